@@ -1,0 +1,583 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy float64 restatement of the reference problem definitions.
+
+PARITY UNPINNED upstream (see ``oracle/__init__.py``).  Every function cites the reference lines it follows.
+Upstream formulas that live in absent third-party packages (Horizon ``utils.toRot``, ``kin_dyn.fSRBD``,
+``utils.double_integrator_with_floating_base``, ``utils.quaterion_product``) are restated from their
+published definitions and tagged UPSTREAM-UNVERIFIED.
+
+Three models:
+  * ``srbd13``  nx=13 nu=6  np=19 -- the BASELINE.json metric model
+  * ``srbd37``  nx=37 nu=24 np=19 -- the reference-faithful SRBD problem (prb.py:16-246)
+  * ``lip30``   nx=30 nu=15 np=11 -- the reference LIP problem (prb.py:248-441)
+
+Costs follow ddp.py:179-226: stage L_k = sum ||residual||^2 + 1e6 * sum ||eq-constraint||^2, terminal
+L_N = sum ||residual||^2 (no constraints).  Everything is expressed as ONE stacked residual vector per node
+(penalties enter as sqrt(1e6) * g) so cost = ||res||^2, gradient = 2 J^T res, Gauss-Newton Hessian = 2 J^T J.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+GRAVITY = 9.81                      # prb.py:243 (static input balances m*9.81), prb.py:317
+CONSTRAINT_WEIGHT = 1e6             # ddp.py:181
+
+
+# ----------------------------------------------------------------------------------------------------------
+# constants (the reference reads these from a URDF + rosparam server that are absent: synthetic, fixed)
+# ----------------------------------------------------------------------------------------------------------
+@dataclass
+class RobotConsts:
+    """Model constants.  Gains are the rosparam defaults of prb.py:142-150 / prb.py:358-362."""
+    m: float = 40.0                                                  # kindyn.mass()            prb.py:92
+    I: np.ndarray = field(default_factory=lambda: np.array(          # CRBA(q)[3:6,3:6]         prb.py:94-95
+        [[2.0, 0.03, -0.02], [0.03, 1.8, 0.04], [-0.02, 0.04, 0.6]]))
+    com: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, 0.88]))   # prb.py:138-139
+    # nc=4 line feet: left upper/lower, right upper/lower (launch:24-25)
+    feet: np.ndarray = field(default_factory=lambda: np.array(
+        [[0.08, 0.1, 0.0], [-0.08, 0.1, 0.0], [0.08, -0.1, 0.0], [-0.08, -0.1, 0.0]]))
+    dt: float = 0.05                                                 # T/ns, prb.py:110 ; wpg.py:20
+    force_scaling: float = 1000.0                                    # prb.py:98
+    r_tracking_gain: float = 1e3                                     # prb.py:142
+    rdot_tracking_gain: float = 1e4                                  # prb.py:145
+    w_tracking_gain: float = 1e4                                     # prb.py:146
+    rel_pos_gain: float = 1e4                                        # prb.py:147
+    force_switch_weight: float = 1e2                                 # prb.py:148
+    min_qddot_gain: float = 1e0                                      # prb.py:149
+    min_f_gain: float = 1e-2                                         # prb.py:150
+    zmp_tracking_gain: float = 1e3                                   # prb.py:360 (LIP)
+    lip_height: float = 0.88                                         # prb.py:317
+    inertia_mode: int = 0       # 0: R o I o R^T element-wise (reference-faithful); 1: R I R^T
+    lever_sign: float = 1.0     # +1: (c_i - r) x f_i (physical, default); -1: (r - c_i) x f_i (App. A.3)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# quaternion helpers (x, y, z, w order; identity = 0,0,0,1 -- prb.py:226)
+# ----------------------------------------------------------------------------------------------------------
+def skew(a):
+    return np.array([[0.0, -a[2], a[1]], [a[2], 0.0, -a[0]], [-a[1], a[0], 0.0]], dtype=np.result_type(a, float))
+
+
+def quat_to_rot(q):
+    """Horizon utils.toRot (prb.py:97).  UPSTREAM-UNVERIFIED: standard xyzw -> matrix, no normalisation."""
+    x, y, z, w = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=np.result_type(q, float))
+
+
+def quat_to_rot_jac(q):
+    """dR/dq_a for a in x,y,z,w (list of four 3x3)."""
+    x, y, z, w = q
+    t = np.result_type(q, float)
+    return [
+        np.array([[0, 2 * y, 2 * z], [2 * y, -4 * x, -2 * w], [2 * z, 2 * w, -4 * x]], dtype=t),
+        np.array([[-4 * y, 2 * x, 2 * w], [2 * x, 0, 2 * z], [-2 * w, 2 * z, -4 * y]], dtype=t),
+        np.array([[-4 * z, -2 * w, 2 * x], [2 * w, -4 * z, 2 * y], [2 * x, 2 * y, 0]], dtype=t),
+        np.array([[0, -2 * z, 2 * y], [2 * z, 0, -2 * x], [-2 * y, 2 * x, 0]], dtype=t)]
+
+
+def quat_mul(q, p):
+    """Horizon utils.quaterion_product (prb.py:187).  UPSTREAM-UNVERIFIED: Hamilton product, xyzw."""
+    qv, qw = q[0:3], q[3]
+    pv, pw = p[0:3], p[3]
+    return np.concatenate([qw * pv + pw * qv + np.cross(qv, pv), [qw * pw - qv @ pv]])
+
+
+def quat_rate(o, w):
+    """odot = 1/2 [w;0] (x) o  (LOCAL_WORLD_ALIGNED, prb.py:107-108).  UPSTREAM-UNVERIFIED."""
+    ov, ow = o[0:3], o[3]
+    return 0.5 * np.concatenate([ow * w + np.cross(w, ov), [-(w @ ov)]])
+
+
+def quat_rate_jac(o, w):
+    """(d odot/d o [4x4], d odot/d w [4x3])."""
+    ov, ow = o[0:3], o[3]
+    Jo = np.zeros((4, 4))
+    Jo[0:3, 0:3] = 0.5 * skew(w)
+    Jo[0:3, 3] = 0.5 * w
+    Jo[3, 0:3] = -0.5 * w
+    Jw = np.zeros((4, 3))
+    Jw[0:3, :] = 0.5 * (ow * np.eye(3) - skew(ov))
+    Jw[3, :] = -0.5 * ov
+    return Jo, Jw
+
+
+# ----------------------------------------------------------------------------------------------------------
+# SRBD accelerations (Horizon kin_dyn.fSRBD, prb.py:99).  UPSTREAM-UNVERIFIED lever-arm sign -> flag.
+# ----------------------------------------------------------------------------------------------------------
+def world_inertia(cst: RobotConsts, o):
+    """I_w and its derivative wrt the quaternion.  prb.py:99 writes ``w_R_b * (I / force_scaling) * w_R_b.T``
+    where CasADi ``*`` is ELEMENT-WISE; inertia_mode=1 gives the physical R I R^T."""
+    R = quat_to_rot(o)
+    dR = quat_to_rot_jac(o)
+    Is = np.asarray(cst.I) / cst.force_scaling
+    if cst.inertia_mode == 0:
+        M = R * Is * R.T
+        dM = [Is * (dR[a] * R.T + R * dR[a].T) for a in range(4)]
+    else:
+        M = R @ Is @ R.T
+        dM = [dR[a] @ Is @ R.T + R @ Is @ dR[a].T for a in range(4)]
+    return M, dM
+
+
+def srbd_acc(cst: RobotConsts, r, o, w, cs, fs):
+    """rddot, wdot for contact points ``cs`` and (scaled) forces ``fs`` (prb.py:92-99, App. A.3)."""
+    ms = cst.m / cst.force_scaling
+    rddot = np.array([0.0, 0.0, -GRAVITY]) + sum(fs) / ms
+    M, _ = world_inertia(cst, o)
+    tau = sum(cst.lever_sign * np.cross(c - r, f) for c, f in zip(cs, fs)) - np.cross(w, M @ w)
+    wdot = np.linalg.solve(M, tau)
+    return rddot, wdot
+
+
+def srbd_acc_jac(cst: RobotConsts, r, o, w, cs, fs):
+    """Jacobians of (rddot, wdot): dict with wdot_r [3x3], wdot_o [3x4], wdot_w [3x3], wdot_c[i], wdot_f[i],
+    rddot_f (scalar 1/ms: d rddot / d f_i = I/ms)."""
+    ms = cst.m / cst.force_scaling
+    M, dM = world_inertia(cst, o)
+    Minv = np.linalg.inv(M)
+    tau = sum(cst.lever_sign * np.cross(c - r, f) for c, f in zip(cs, fs)) - np.cross(w, M @ w)
+    wdot = Minv @ tau
+    s = cst.lever_sign
+    out = {
+        "rddot_f": 1.0 / ms,
+        "wdot_r": Minv @ (s * sum(skew(f) for f in fs)),
+        "wdot_w": Minv @ (skew(M @ w) - skew(w) @ M),
+        "wdot_c": [Minv @ (-s * skew(f)) for f in fs],
+        "wdot_f": [Minv @ (s * skew(c - r)) for c in cs],
+    }
+    Jo = np.zeros((3, 4))
+    for a in range(4):
+        Jo[:, a] = -Minv @ (dM[a] @ wdot + np.cross(w, dM[a] @ w))
+    out["wdot_o"] = Jo
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# generic model interface
+# ----------------------------------------------------------------------------------------------------------
+class _Rows:
+    """Accumulates residual rows and their Jacobians."""
+
+    def __init__(self, nx, nu):
+        self.nx, self.nu = nx, nu
+        self.r, self.Jx, self.Ju = [], [], []
+
+    def add(self, val, Jx=None, Ju=None):
+        val = np.atleast_1d(np.asarray(val, dtype=float))
+        n = val.shape[0]
+        self.r.append(val)
+        self.Jx.append(np.zeros((n, self.nx)) if Jx is None else np.asarray(Jx, dtype=float).reshape(n, self.nx))
+        self.Ju.append(np.zeros((n, self.nu)) if Ju is None else np.asarray(Ju, dtype=float).reshape(n, self.nu))
+
+    def stack(self):
+        return np.concatenate(self.r), np.vstack(self.Jx), np.vstack(self.Ju)
+
+
+class Model:
+    """f: x+ = x + dt*xdot(x,u[,p])  (explicit Euler, ddp.py:228-230);
+    residual(x,u,p,k): stacked residual vector of node k (u=None -> terminal node, ddp.py:216-226)."""
+    name = "?"
+    nx = nu = np_ = 0
+
+    def __init__(self, cst: RobotConsts | None = None):
+        self.cst = cst if cst is not None else RobotConsts()
+
+    # --- to be provided -------------------------------------------------------------------------------
+    def f(self, x, u, p):
+        raise NotImplementedError
+
+    def f_jac(self, x, u, p):
+        raise NotImplementedError
+
+    def residual_jac(self, x, u, p, k):
+        """-> (res, Jx, Ju).  ``u is None`` marks the terminal node."""
+        raise NotImplementedError
+
+    # --- derived ------------------------------------------------------------------------------------------
+    def residual(self, x, u, p, k):
+        return self.residual_jac(x, u, p, k)[0]
+
+    def cost(self, x, u, p, k):
+        r = self.residual(x, u, p, k)
+        return float(r @ r)
+
+    def cost_derivs(self, x, u, p, k):
+        """-> L, lx, lu, lxx, lux, luu (Gauss-Newton Hessian 2 J^T J)."""
+        r, Jx, Ju = self.residual_jac(x, u, p, k)
+        return float(r @ r), 2 * Jx.T @ r, 2 * Ju.T @ r, 2 * Jx.T @ Jx, 2 * Ju.T @ Jx, 2 * Ju.T @ Ju
+
+    def initial_state(self):
+        raise NotImplementedError
+
+    def static_input(self):
+        raise NotImplementedError
+
+    def default_params(self, N):
+        raise NotImplementedError
+
+
+# ----------------------------------------------------------------------------------------------------------
+# srbd13 -- metric model: x = r|o|rdot|w, u = f_L|f_R, contacts are per-knot parameters
+# ----------------------------------------------------------------------------------------------------------
+class SRBD13(Model):
+    name = "srbd13"
+    nx, nu, np_ = 13, 6, 19
+    R_, O_, RD_, W_ = slice(0, 3), slice(3, 7), slice(7, 10), slice(10, 13)
+    # p = rdot_ref(3) | w_ref(3) | otg(1) | oref(4) | c_L(3) | c_R(3) | sw_L | sw_R
+    P_RDREF, P_WREF, P_OTG, P_OREF = slice(0, 3), slice(3, 6), 6, slice(7, 11)
+    P_C = (slice(11, 14), slice(14, 17))
+    P_SW = (17, 18)
+
+    def _split(self, x, u, p):
+        cs = [p[self.P_C[0]], p[self.P_C[1]]]
+        fs = [u[0:3], u[3:6]]
+        return x[self.R_], x[self.O_], x[self.RD_], x[self.W_], cs, fs
+
+    def f(self, x, u, p):
+        r, o, rd, w, cs, fs = self._split(x, u, p)
+        rddot, wdot = srbd_acc(self.cst, r, o, w, cs, fs)
+        dt = self.cst.dt
+        return np.concatenate([r + dt * rd, o + dt * quat_rate(o, w), rd + dt * rddot, w + dt * wdot])
+
+    def f_jac(self, x, u, p):
+        r, o, rd, w, cs, fs = self._split(x, u, p)
+        dt = self.cst.dt
+        J = srbd_acc_jac(self.cst, r, o, w, cs, fs)
+        Jo, Jw = quat_rate_jac(o, w)
+        fx = np.eye(13)
+        fu = np.zeros((13, 6))
+        fx[self.R_, self.RD_] += dt * np.eye(3)
+        fx[self.O_, self.O_] += dt * Jo
+        fx[self.O_, self.W_] += dt * Jw
+        fx[self.W_, self.R_] += dt * J["wdot_r"]
+        fx[self.W_, self.O_] += dt * J["wdot_o"]
+        fx[self.W_, self.W_] += dt * J["wdot_w"]
+        for i in range(2):
+            fu[self.RD_, 3 * i:3 * i + 3] = dt * J["rddot_f"] * np.eye(3)
+            fu[self.W_, 3 * i:3 * i + 3] = dt * J["wdot_f"][i]
+        return fx, fu
+
+    def residual_jac(self, x, u, p, k):
+        c = self.cst
+        rows = _Rows(13, 6)
+        r, o, rd, w = x[self.R_], x[self.O_], x[self.RD_], x[self.W_]
+        terminal = u is None
+        if terminal or k >= 1:                                  # nodes 1..ns (prb.py:184-191)
+            _srbd_state_rows(rows, c, r, o, rd, w, p[self.P_RDREF], p[self.P_WREF], p[self.P_OTG],
+                             p[self.P_OREF], self.R_, self.O_, self.RD_, self.W_)
+        if not terminal:                                        # nodes 0..ns-1 (prb.py:200-204)
+            cs = [p[self.P_C[0]], p[self.P_C[1]]]
+            fs = [u[0:3], u[3:6]]
+            rddot, wdot = srbd_acc(c, r, o, w, cs, fs)
+            J = srbd_acc_jac(c, r, o, w, cs, fs)
+            g = np.sqrt(c.min_qddot_gain)
+            Jx = np.zeros((6, 13))
+            Ju = np.zeros((6, 6))
+            Jx[3:6, self.R_] = J["wdot_r"]
+            Jx[3:6, self.O_] = J["wdot_o"]
+            Jx[3:6, self.W_] = J["wdot_w"]
+            for i in range(2):
+                Ju[0:3, 3 * i:3 * i + 3] = J["rddot_f"] * np.eye(3)
+                Ju[3:6, 3 * i:3 * i + 3] = J["wdot_f"][i]
+            rows.add(g * np.concatenate([rddot, wdot]), g * Jx, g * Ju)          # min_qddot  prb.py:200
+            for i in range(2):
+                _force_rows(rows, c, fs[i], p[self.P_SW[i]], 3 * i)
+        return rows.stack()
+
+    def initial_state(self):
+        return np.concatenate([self.cst.com, [0, 0, 0, 1.0], np.zeros(6)])        # prb.py:224-240 reduced
+
+    def static_input(self):
+        fz = self.cst.m * GRAVITY / self.cst.force_scaling / 2                    # prb.py:243 with 2 contacts
+        return np.array([0, 0, fz, 0, 0, fz])
+
+    def foot_centers(self):
+        feet = np.asarray(self.cst.feet)
+        return 0.5 * (feet[0] + feet[1]), 0.5 * (feet[2] + feet[3])
+
+    def default_params(self, N):
+        P = np.zeros((N + 1, 19))
+        P[:, self.P_OTG] = 1e1                                                     # prb.py:144
+        P[:, self.P_OREF] = [-0.0, -0.0, -0.0, 1.0]                                # prb.py:186
+        cl, cr = self.foot_centers()
+        P[:, self.P_C[0]] = cl
+        P[:, self.P_C[1]] = cr
+        P[:, self.P_SW[0]] = 1.0
+        P[:, self.P_SW[1]] = 1.0                                                   # prb.py:163
+        return P
+
+
+def _srbd_state_rows(rows, c, r, o, rd, w, rdot_ref, w_ref, otg, oref, R_, O_, RD_, W_):
+    nx = rows.nx
+    J = np.zeros((1, nx)); J[0, R_.start + 2] = 1.0
+    g = np.sqrt(c.r_tracking_gain)
+    rows.add(g * (r[2] - c.com[2]), g * J)                                         # rz_tracking  prb.py:184
+    e = quat_mul(o, oref)                                                          # prb.py:187
+    Je = np.zeros((4, nx))
+    Je[0:3, O_.start:O_.start + 3] = oref[3] * np.eye(3) - skew(oref[0:3])
+    Je[0:3, O_.start + 3] = oref[0:3]
+    Je[3, O_.start:O_.start + 3] = -oref[0:3]
+    Je[3, O_.start + 3] = oref[3]
+    rows.add(otg * e[0:3], otg * Je[0:3])                                          # o_tracking_xyz prb.py:188
+    rows.add(otg * (e[3] - 1.0), otg * Je[3:4])                                    # o_tracking_w   prb.py:189
+    J = np.zeros((3, nx)); J[:, RD_] = np.eye(3)
+    g = np.sqrt(c.rdot_tracking_gain)
+    rows.add(g * (rd - rdot_ref), g * J)                                           # rdot_tracking prb.py:190
+    J = np.zeros((3, nx)); J[:, W_] = np.eye(3)
+    g = np.sqrt(c.w_tracking_gain)
+    rows.add(g * (w - w_ref), g * J)                                               # w_tracking    prb.py:191
+
+
+def _force_rows(rows, c, f, sw, ucol):
+    J = np.zeros((3, rows.nu)); J[:, ucol:ucol + 3] = np.eye(3)
+    g = c.force_scaling * np.sqrt(c.min_f_gain)
+    rows.add(g * f, None, g * J)                                                   # min_f_i     prb.py:202
+    g = c.force_scaling * np.sqrt(c.force_switch_weight) * (1.0 - sw)
+    rows.add(g * f, None, g * J)                                                   # f_i_active  prb.py:203-204
+
+
+def _contact_penalty_rows(rows, cs, cds, c_ref, sw, c_idx, cd_idx, contact_model):
+    """Equality constraints as sqrt(1e6)-weighted residuals (ddp.py:195-196; prb.py:166-170, :179-181)."""
+    nx = rows.nx
+    g = np.sqrt(CONSTRAINT_WEIGHT)
+    nc = len(cs)
+    if contact_model > 1:
+        for i in range(1, contact_model):                                           # relative_vel_left_i
+            J = np.zeros((2, nx)); J[0, cd_idx[0]] = J[1, cd_idx[0] + 1] = 1; J[0, cd_idx[i]] = J[1, cd_idx[i] + 1] = -1
+            rows.add(g * (cds[0][0:2] - cds[i][0:2]), g * J)
+        for i in range(contact_model + 1, 2 * contact_model):                       # relative_vel_right_i
+            b = contact_model
+            J = np.zeros((2, nx)); J[0, cd_idx[b]] = J[1, cd_idx[b] + 1] = 1; J[0, cd_idx[i]] = J[1, cd_idx[i] + 1] = -1
+            rows.add(g * (cds[b][0:2] - cds[i][0:2]), g * J)
+    for i in range(nc):
+        J = np.zeros((1, nx)); J[0, c_idx[i] + 2] = 1
+        rows.add(g * (cs[i][2] - c_ref[i]), g * J)                                  # cz_tracking_i
+        J = np.zeros((2, nx)); J[0, cd_idx[i]] = J[1, cd_idx[i] + 1] = sw[i]
+        rows.add(g * sw[i] * cds[i][0:2], g * J)                                    # cdotxy_tracking_i
+
+
+def _rel_pos_rows(rows, c, cs, c_idx, feet):
+    """rel_pos_{y,x}_1_4 and _3_6 (prb.py:192-199) with d1 = p2-p0, d2 = p3-p1 (prb.py:153-154)."""
+    nx = rows.nx
+    g = np.sqrt(c.rel_pos_gain)
+    d1 = -(feet[0][0:2] - feet[2][0:2])
+    d2 = -(feet[1][0:2] - feet[3][0:2])
+    for (a, b, d) in ((0, 2, d1), (1, 3, d2)):
+        for comp in (1, 0):                                                         # y first, then x
+            J = np.zeros((1, nx)); J[0, c_idx[a] + comp] = -1; J[0, c_idx[b] + comp] = 1
+            rows.add(g * (-cs[a][comp] + cs[b][comp] - d[comp]), g * J)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# srbd37 -- reference-faithful SRBD (prb.py:16-246), nc = 4
+# ----------------------------------------------------------------------------------------------------------
+class SRBD37(Model):
+    name = "srbd37"
+    nx, nu, np_ = 37, 24, 19
+    nc, contact_model = 4, 2                                                        # launch:16-17
+    R_, O_, RD_, W_ = slice(0, 3), slice(3, 7), slice(19, 22), slice(22, 25)
+    C_IDX = [7, 10, 13, 16]
+    CD_IDX = [25, 28, 31, 34]
+    # p = rdot_ref | w_ref | otg | (c_ref_i, sw_i) x4 | oref   (creation order)
+    P_RDREF, P_WREF, P_OTG, P_OREF = slice(0, 3), slice(3, 6), 6, slice(15, 19)
+
+    @staticmethod
+    def p_cref(i):
+        return 7 + 2 * i
+
+    @staticmethod
+    def p_sw(i):
+        return 8 + 2 * i
+
+    def _split(self, x, u):
+        cs = [x[i:i + 3] for i in self.C_IDX]
+        cds = [x[i:i + 3] for i in self.CD_IDX]
+        cdd = [u[6 * i:6 * i + 3] for i in range(4)]
+        fs = [u[6 * i + 3:6 * i + 6] for i in range(4)]                              # interleaved prb.py:66-68
+        return x[self.R_], x[self.O_], x[self.RD_], x[self.W_], cs, cds, cdd, fs
+
+    def f(self, x, u, p):
+        r, o, rd, w, cs, cds, cdd, fs = self._split(x, u)
+        rddot, wdot = srbd_acc(self.cst, r, o, w, cs, fs)
+        xdot = np.concatenate([rd, quat_rate(o, w)] + cds + [rddot, wdot] + cdd)    # App. A.3
+        return x + self.cst.dt * xdot
+
+    def f_jac(self, x, u, p):
+        r, o, rd, w, cs, cds, cdd, fs = self._split(x, u)
+        dt = self.cst.dt
+        J = srbd_acc_jac(self.cst, r, o, w, cs, fs)
+        Jo, Jw = quat_rate_jac(o, w)
+        A = np.zeros((37, 37))
+        B = np.zeros((37, 24))
+        A[self.R_, self.RD_] = np.eye(3)
+        A[self.O_, self.O_] = Jo
+        A[self.O_, self.W_] = Jw
+        for i in range(4):
+            A[self.C_IDX[i]:self.C_IDX[i] + 3, self.CD_IDX[i]:self.CD_IDX[i] + 3] = np.eye(3)
+            A[self.W_, self.C_IDX[i]:self.C_IDX[i] + 3] = J["wdot_c"][i]
+            B[self.RD_, 6 * i + 3:6 * i + 6] = J["rddot_f"] * np.eye(3)
+            B[self.W_, 6 * i + 3:6 * i + 6] = J["wdot_f"][i]
+            B[self.CD_IDX[i]:self.CD_IDX[i] + 3, 6 * i:6 * i + 3] = np.eye(3)
+        A[self.W_, self.R_] = J["wdot_r"]
+        A[self.W_, self.O_] = J["wdot_o"]
+        A[self.W_, self.W_] = J["wdot_w"]
+        return np.eye(37) + dt * A, dt * B
+
+    def residual_jac(self, x, u, p, k):
+        c = self.cst
+        rows = _Rows(37, 24)
+        terminal = u is None
+        xs = x
+        r, o, rd, w = xs[self.R_], xs[self.O_], xs[self.RD_], xs[self.W_]
+        cs = [xs[i:i + 3] for i in self.C_IDX]
+        cds = [xs[i:i + 3] for i in self.CD_IDX]
+        if terminal or k >= 1:
+            _srbd_state_rows(rows, c, r, o, rd, w, p[self.P_RDREF], p[self.P_WREF], p[self.P_OTG],
+                             p[self.P_OREF], self.R_, self.O_, self.RD_, self.W_)
+            _rel_pos_rows(rows, c, cs, self.C_IDX, np.asarray(c.feet))
+        if not terminal:
+            cdd = [u[6 * i:6 * i + 3] for i in range(4)]
+            fs = [u[6 * i + 3:6 * i + 6] for i in range(4)]
+            rddot, wdot = srbd_acc(c, r, o, w, cs, fs)
+            J = srbd_acc_jac(c, r, o, w, cs, fs)
+            g = np.sqrt(c.min_qddot_gain)
+            Jx = np.zeros((18, 37))
+            Ju = np.zeros((18, 24))
+            Jx[3:6, self.R_] = J["wdot_r"]
+            Jx[3:6, self.O_] = J["wdot_o"]
+            Jx[3:6, self.W_] = J["wdot_w"]
+            for i in range(4):
+                Jx[3:6, self.C_IDX[i]:self.C_IDX[i] + 3] = J["wdot_c"][i]
+                Ju[0:3, 6 * i + 3:6 * i + 6] = J["rddot_f"] * np.eye(3)
+                Ju[3:6, 6 * i + 3:6 * i + 6] = J["wdot_f"][i]
+                Ju[6 + 3 * i:9 + 3 * i, 6 * i:6 * i + 3] = np.eye(3)
+            rows.add(g * np.concatenate([rddot, wdot] + cdd), g * Jx, g * Ju)       # min_qddot prb.py:200
+            for i in range(4):
+                _force_rows(rows, c, fs[i], p[self.p_sw(i)], 6 * i + 3)
+            _contact_penalty_rows(rows, cs, cds, [p[self.p_cref(i)] for i in range(4)],
+                                  [p[self.p_sw(i)] for i in range(4)], self.C_IDX, self.CD_IDX, self.contact_model)
+        return rows.stack()
+
+    def initial_state(self):
+        feet = np.asarray(self.cst.feet)
+        return np.concatenate([self.cst.com, [0, 0, 0, 1.0], feet.reshape(-1), np.zeros(18)])   # prb.py:224-240
+
+    def static_input(self):
+        fz = self.cst.m * GRAVITY / self.cst.force_scaling / 4                      # prb.py:242-246
+        return np.tile([0, 0, 0, 0, 0, fz], 4)
+
+    def default_params(self, N):
+        P = np.zeros((N + 1, 19))
+        P[:, self.P_OTG] = 1e1
+        feet = np.asarray(self.cst.feet)
+        for i in range(4):
+            P[:, self.p_cref(i)] = feet[i][2]                                       # prb.py:161
+            P[:, self.p_sw(i)] = 1.0                                                # prb.py:163
+        P[:, self.P_OREF] = [-0.0, -0.0, -0.0, 1.0]
+        return P
+
+
+# ----------------------------------------------------------------------------------------------------------
+# lip30 -- reference LIP problem (prb.py:248-441), linear dynamics + quadratic cost
+# ----------------------------------------------------------------------------------------------------------
+class LIP30(Model):
+    name = "lip30"
+    nx, nu, np_ = 30, 15, 11
+    nc, contact_model = 4, 2
+    R_, RD_ = slice(0, 3), slice(15, 18)
+    C_IDX = [3, 6, 9, 12]
+    CD_IDX = [18, 21, 24, 27]
+    P_RDREF = slice(0, 3)
+
+    @staticmethod
+    def p_cref(i):
+        return 3 + 2 * i
+
+    @staticmethod
+    def p_sw(i):
+        return 4 + 2 * i
+
+    def _AB(self):
+        eta2 = GRAVITY / self.cst.lip_height                                        # prb.py:317
+        A = np.zeros((30, 30)); B = np.zeros((30, 15))
+        A[0:15, 15:30] = np.eye(15)                                                 # qdot
+        A[self.RD_, self.R_] = eta2 * np.eye(3)                                     # rddot = eta2 (r - z) - g
+        B[self.RD_, 0:3] = -eta2 * np.eye(3)
+        for i in range(4):
+            B[self.CD_IDX[i]:self.CD_IDX[i] + 3, 3 + 3 * i:6 + 3 * i] = np.eye(3)
+        b = np.zeros(30); b[self.RD_.start + 2] = -GRAVITY                          # prb.py:318
+        return A, B, b
+
+    def f(self, x, u, p):
+        A, B, b = self._AB()
+        return x + self.cst.dt * (A @ x + B @ u + b)
+
+    def f_jac(self, x, u, p):
+        A, B, _ = self._AB()
+        return np.eye(30) + self.cst.dt * A, self.cst.dt * B
+
+    def residual_jac(self, x, u, p, k):
+        c = self.cst
+        rows = _Rows(30, 15)
+        terminal = u is None
+        r, rd = x[self.R_], x[self.RD_]
+        cs = [x[i:i + 3] for i in self.C_IDX]
+        cds = [x[i:i + 3] for i in self.CD_IDX]
+        mean_c = 0.25 * (cs[0] + cs[1] + cs[2] + cs[3])
+        Jmean = np.zeros((3, 30))
+        for i in self.C_IDX:
+            Jmean[:, i:i + 3] = 0.25 * np.eye(3)
+        if terminal or k >= 1:
+            g = np.sqrt(c.r_tracking_gain)
+            J = np.zeros((1, 30)); J[0, 2] = 1
+            rows.add(g * (r[2] - c.com[2]), g * J)                                  # rz_tracking prb.py:390
+            J = np.zeros((2, 30)); J[:, 0:2] = np.eye(2); J -= Jmean[0:2]
+            rows.add(g * (r[0:2] - mean_c[0:2]), g * J)                             # rxy_tracking prb.py:391
+            g = np.sqrt(c.rdot_tracking_gain)
+            J = np.zeros((3, 30)); J[:, self.RD_] = np.eye(3)
+            rows.add(g * (rd - p[self.P_RDREF]), g * J)                             # rdot_tracking prb.py:392
+        if not terminal:
+            z = u[0:3]
+            g = np.sqrt(c.zmp_tracking_gain)
+            Ju = np.zeros((3, 15)); Ju[:, 0:3] = np.eye(3)
+            rows.add(g * (z - mean_c), -g * Jmean, g * Ju)                          # zmp_tracking prb.py:393
+        if terminal or k >= 1:
+            _rel_pos_rows(rows, c, cs, self.C_IDX, np.asarray(c.feet))              # prb.py:394-401
+        if not terminal:
+            eta2 = GRAVITY / c.lip_height
+            g = np.sqrt(c.min_qddot_gain)
+            rddot = eta2 * (r - u[0:3]) - np.array([0, 0, GRAVITY])
+            Jx = np.zeros((15, 30)); Ju = np.zeros((15, 15))
+            Jx[0:3, self.R_] = eta2 * np.eye(3)
+            Ju[0:3, 0:3] = -eta2 * np.eye(3)
+            Ju[3:15, 3:15] = np.eye(12)
+            rows.add(g * np.concatenate([rddot, u[3:15]]), g * Jx, g * Ju)          # min_qddot prb.py:402
+            _contact_penalty_rows(rows, cs, cds, [p[self.p_cref(i)] for i in range(4)],
+                                  [p[self.p_sw(i)] for i in range(4)], self.C_IDX, self.CD_IDX, self.contact_model)
+        return rows.stack()
+
+    def initial_state(self):
+        feet = np.asarray(self.cst.feet)
+        return np.concatenate([self.cst.com, feet.reshape(-1), np.zeros(15)])       # prb.py:420-433
+
+    def static_input(self):
+        return np.concatenate([[self.cst.com[0], self.cst.com[1], 0.0], np.zeros(12)])   # prb.py:435-441
+
+    def default_params(self, N):
+        P = np.zeros((N + 1, 11))
+        feet = np.asarray(self.cst.feet)
+        for i in range(4):
+            P[:, self.p_cref(i)] = feet[i][2]
+            P[:, self.p_sw(i)] = 1.0
+        return P
+
+
+MODELS = {"srbd13": SRBD13, "srbd37": SRBD37, "lip30": LIP30}
+
+
+def make_model(name: str, cst: RobotConsts | None = None) -> Model:
+    return MODELS[name](cst)

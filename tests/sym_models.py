@@ -1,0 +1,162 @@
+"""Independent sympy restatement of SURVEY.md App. A (dynamics + residuals), used ONLY to pin the oracle's
+hand-written Jacobians by symbolic differentiation.  Written from the equations, not from oracle/models.py."""
+import functools
+
+import numpy as np
+import sympy as sp
+
+G = sp.Float(9.81)
+
+
+def _toRot(q):
+    x, y, z, w = q
+    return sp.Matrix([[1 - 2 * (y**2 + z**2), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x**2 + z**2), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x**2 + y**2)]])
+
+
+def _qmul(q, p):
+    qv, qw = sp.Matrix(q[0:3]), q[3]
+    pv, pw = sp.Matrix(p[0:3]), p[3]
+    v = qw * pv + pw * qv + qv.cross(pv)
+    return sp.Matrix([v[0], v[1], v[2], qw * pw - qv.dot(pv)])
+
+
+def _srbd(cst, r, o, w, cs, fs):
+    s = cst.force_scaling
+    ms = cst.m / s
+    Is = sp.Matrix(np.asarray(cst.I) / s)
+    R = _toRot(o)
+    if cst.inertia_mode == 0:
+        M = sp.Matrix(3, 3, lambda i, j: R[i, j] * Is[i, j] * R[j, i])
+    else:
+        M = R * Is * R.T
+    rddot = sp.Matrix([0, 0, -G])
+    tau = sp.zeros(3, 1)
+    for c, f in zip(cs, fs):
+        rddot += f / ms
+        tau += cst.lever_sign * (c - r).cross(f)
+    tau -= w.cross(M * w)
+    wdot = (M.adjugate() / M.det()) * tau
+    odot = sp.Rational(1, 2) * _qmul(sp.Matrix([w[0], w[1], w[2], 0]), o)
+    return rddot, wdot, odot
+
+
+def _state_res(cst, r, o, rd, w, rdot_ref, w_ref, otg, oref):
+    e = _qmul(o, oref)
+    return [sp.sqrt(cst.r_tracking_gain) * (r[2] - cst.com[2]),
+            otg * e[0], otg * e[1], otg * e[2], otg * (e[3] - 1),
+            *(sp.sqrt(cst.rdot_tracking_gain) * (rd - rdot_ref)),
+            *(sp.sqrt(cst.w_tracking_gain) * (w - w_ref))]
+
+
+def _force_res(cst, f, sw):
+    g1 = cst.force_scaling * sp.sqrt(cst.min_f_gain)
+    g2 = cst.force_scaling * sp.sqrt(cst.force_switch_weight)
+    return [*(g1 * f), *(g2 * (1 - sw) * f)]
+
+
+def _penalties(cs, cds, cref, sw):
+    g = sp.sqrt(1e6)
+    out = [*(g * (cds[0][0:2, 0] - cds[1][0:2, 0])), *(g * (cds[2][0:2, 0] - cds[3][0:2, 0]))]
+    for i in range(4):
+        out.append(g * (cs[i][2] - cref[i]))
+        out += [g * sw[i] * cds[i][0], g * sw[i] * cds[i][1]]
+    return out
+
+
+def _relpos(cst, cs):
+    feet = np.asarray(cst.feet)
+    d1 = feet[2][0:2] - feet[0][0:2]
+    d2 = feet[3][0:2] - feet[1][0:2]
+    g = sp.sqrt(cst.rel_pos_gain)
+    return [g * (-cs[0][1] + cs[2][1] - d1[1]), g * (-cs[0][0] + cs[2][0] - d1[0]),
+            g * (-cs[1][1] + cs[3][1] - d2[1]), g * (-cs[1][0] + cs[3][0] - d2[0])]
+
+
+def _build(name, cst):
+    if name == "srbd13":
+        nx, nu, npar = 13, 6, 19
+    elif name == "srbd37":
+        nx, nu, npar = 37, 24, 19
+    else:
+        nx, nu, npar = 30, 15, 11
+    x = sp.Matrix(sp.symbols(f"x0:{nx}"))
+    u = sp.Matrix(sp.symbols(f"u0:{nu}"))
+    p = sp.Matrix(sp.symbols(f"p0:{npar}"))
+    dt = cst.dt
+    if name == "srbd13":
+        r, o, rd, w = x[0:3, 0], x[3:7, 0], x[7:10, 0], x[10:13, 0]
+        cs = [p[11:14, 0], p[14:17, 0]]
+        fs = [u[0:3, 0], u[3:6, 0]]
+        rddot, wdot, odot = _srbd(cst, r, o, w, cs, fs)
+        xdot = sp.Matrix([*rd, *odot, *rddot, *wdot])
+        sres = _state_res(cst, r, o, rd, w, p[0:3, 0], p[3:6, 0], p[6], p[7:11, 0])
+        ires = [*(sp.sqrt(cst.min_qddot_gain) * sp.Matrix([*rddot, *wdot]))]
+        for i in range(2):
+            ires += _force_res(cst, fs[i], p[17 + i])
+    elif name == "srbd37":
+        r, o, rd, w = x[0:3, 0], x[3:7, 0], x[19:22, 0], x[22:25, 0]
+        cs = [x[7 + 3 * i:10 + 3 * i, 0] for i in range(4)]
+        cds = [x[25 + 3 * i:28 + 3 * i, 0] for i in range(4)]
+        cdd = [u[6 * i:6 * i + 3, 0] for i in range(4)]
+        fs = [u[6 * i + 3:6 * i + 6, 0] for i in range(4)]
+        rddot, wdot, odot = _srbd(cst, r, o, w, cs, fs)
+        xdot = sp.Matrix([*rd, *odot, *cds[0], *cds[1], *cds[2], *cds[3], *rddot, *wdot,
+                          *cdd[0], *cdd[1], *cdd[2], *cdd[3]])
+        sres = _state_res(cst, r, o, rd, w, p[0:3, 0], p[3:6, 0], p[6], p[15:19, 0]) + _relpos(cst, cs)
+        ires = [*(sp.sqrt(cst.min_qddot_gain) * sp.Matrix([*rddot, *wdot, *cdd[0], *cdd[1], *cdd[2], *cdd[3]]))]
+        for i in range(4):
+            ires += _force_res(cst, fs[i], p[8 + 2 * i])
+        ires += _penalties(cs, cds, [p[7 + 2 * i] for i in range(4)], [p[8 + 2 * i] for i in range(4)])
+    else:
+        r, rd = x[0:3, 0], x[15:18, 0]
+        cs = [x[3 + 3 * i:6 + 3 * i, 0] for i in range(4)]
+        cds = [x[18 + 3 * i:21 + 3 * i, 0] for i in range(4)]
+        z = u[0:3, 0]
+        cdd = [u[3 + 3 * i:6 + 3 * i, 0] for i in range(4)]
+        eta2 = 9.81 / cst.lip_height
+        rddot = eta2 * (r - z) - sp.Matrix([0, 0, G])
+        xdot = sp.Matrix([*rd, *cds[0], *cds[1], *cds[2], *cds[3], *rddot, *cdd[0], *cdd[1], *cdd[2], *cdd[3]])
+        mean_c = (cs[0] + cs[1] + cs[2] + cs[3]) / 4
+        sres = [sp.sqrt(cst.r_tracking_gain) * (r[2] - cst.com[2]),
+                *(sp.sqrt(cst.r_tracking_gain) * (r[0:2, 0] - mean_c[0:2, 0])),
+                *(sp.sqrt(cst.rdot_tracking_gain) * (rd - p[0:3, 0]))] + _relpos(cst, cs)
+        ires = [*(sp.sqrt(cst.zmp_tracking_gain) * (z - mean_c)),
+                *(sp.sqrt(cst.min_qddot_gain) * sp.Matrix([*rddot, *cdd[0], *cdd[1], *cdd[2], *cdd[3]]))]
+        ires += _penalties(cs, cds, [p[3 + 2 * i] for i in range(4)], [p[4 + 2 * i] for i in range(4)])
+    f = x + dt * xdot
+    z_all = sp.Matrix([*x, *u])
+    out = {}
+    args = (list(x), list(u), list(p))
+    lam = lambda e: sp.lambdify(args, e, "numpy", cse=True)
+    out["f"] = lam(f)
+    out["F"] = lam(f.jacobian(z_all))
+    # residual vectors and their SYMBOLIC Jacobians; costs / gradients / GN Hessians are assembled numerically
+    ires_m, sres_m = sp.Matrix(ires), sp.Matrix(sres)
+    out["ires"], out["sres"] = lam(ires_m), lam(sres_m)
+    out["Ji"], out["Js"] = lam(ires_m.jacobian(z_all)), lam(sres_m.jacobian(z_all))
+    out["nx"] = nx
+    return out
+
+@functools.lru_cache(maxsize=None)
+def symbolic(name, inertia_mode=0, lever_sign=1.0):
+    from oracle.models import RobotConsts
+    cst = RobotConsts(inertia_mode=inertia_mode, lever_sign=lever_sign)
+    return _build(name, cst), cst
+
+
+def cost_terms(sym, key, x, u, p):
+    """(L, gradient wrt [x;u], GN Hessian) of node class key in {'0','k','N'} from the symbolic residuals."""
+    nx = sym["nx"]
+    ri = np.asarray(sym["ires"](x, u, p), dtype=float).reshape(-1)
+    rs = np.asarray(sym["sres"](x, u, p), dtype=float).reshape(-1)
+    Ji = np.asarray(sym["Ji"](x, u, p), dtype=float)
+    Js = np.asarray(sym["Js"](x, u, p), dtype=float)
+    if key == "0":
+        r, J = ri, Ji
+    elif key == "k":
+        r, J = np.concatenate([ri, rs]), np.vstack([Ji, Js])
+    else:
+        r, J = rs, Js[:, :nx]
+    return float(r @ r), 2 * J.T @ r, 2 * J.T @ J

@@ -1,0 +1,128 @@
+"""Pins for the oracle's model restatement: sympy symbolic differentiation and finite
+differences of the App. A equations vs the hand-written numpy Jacobians, plus in-tree consistency facts."""
+import numpy as np
+import pytest
+
+from oracle import models
+from tests import sym_models
+
+
+def _rand_point(m, rng, N=20):
+    x = m.initial_state().astype(float).copy()
+    x += 0.05 * rng.standard_normal(m.nx)
+    u = m.static_input().astype(float) + 0.05 * rng.standard_normal(m.nu)
+    P = m.default_params(N)
+    p = P[3].copy() + 0.05 * rng.standard_normal(m.np_)
+    return x, u, p
+
+
+CASES = [("srbd13", 0, 1.0), ("srbd13", 0, -1.0), ("srbd37", 0, 1.0), ("lip30", 0, 1.0)]
+
+
+@pytest.mark.parametrize("name,imode,lever", CASES)
+def test_dynamics_and_costs_match_sympy(name, imode, lever):
+    sym, cst = sym_models.symbolic(name, imode, lever)
+    m = models.make_model(name, cst)
+    rng = np.random.default_rng(7)
+    for _ in range(3):
+        x, u, p = _rand_point(m, rng)
+        f_ref = np.asarray(sym["f"](x, u, p)).reshape(-1)
+        F_ref = np.asarray(sym["F"](x, u, p))
+        np.testing.assert_allclose(m.f(x, u, p), f_ref, rtol=1e-12, atol=1e-12)
+        fx, fu = m.f_jac(x, u, p)
+        np.testing.assert_allclose(np.hstack([fx, fu]), F_ref, rtol=1e-10, atol=1e-10)
+        for key, k, uu in (("0", 0, u), ("k", 3, u), ("N", 20, None)):
+            L, lx, lu, lxx, lux, luu = m.cost_derivs(x, uu, p, k)
+            Lr, g, H = sym_models.cost_terms(sym, key, x, u, p)
+            assert abs(L - Lr) <= 1e-10 * max(1.0, abs(Lr))
+            scale = max(1.0, np.max(np.abs(g)))
+            hs = max(1.0, np.max(np.abs(H)))
+            if uu is None:
+                np.testing.assert_allclose(lx, g, rtol=1e-9, atol=1e-9 * scale)
+                np.testing.assert_allclose(lxx, H, rtol=1e-9, atol=1e-9 * hs)
+            else:
+                np.testing.assert_allclose(np.concatenate([lx, lu]), g, rtol=1e-9, atol=1e-9 * scale)
+                Hm = np.block([[lxx, lux.T], [lux, luu]])
+                np.testing.assert_allclose(Hm, H, rtol=1e-9, atol=1e-9 * hs)
+
+
+@pytest.mark.parametrize("name,imode,lever", [("srbd13", 0, 1.0), ("srbd13", 1, -1.0), ("srbd37", 0, 1.0),
+                                              ("srbd37", 1, 1.0), ("lip30", 0, 1.0)])
+def test_jacobians_match_finite_differences(name, imode, lever):
+    m = models.make_model(name, models.RobotConsts(inertia_mode=imode, lever_sign=lever))
+    rng = np.random.default_rng(3)
+    x, u, p = _rand_point(m, rng)
+    fx, fu = m.f_jac(x, u, p)
+    h = 1e-6
+    for j in range(m.nx):
+        e = np.zeros(m.nx); e[j] = h
+        col = (m.f(x + e, u, p) - m.f(x - e, u, p)) / (2 * h)
+        np.testing.assert_allclose(fx[:, j], col, rtol=1e-6, atol=1e-7)
+    for j in range(m.nu):
+        e = np.zeros(m.nu); e[j] = h
+        col = (m.f(x, u + e, p) - m.f(x, u - e, p)) / (2 * h)
+        np.testing.assert_allclose(fu[:, j], col, rtol=1e-6, atol=1e-7)
+    r, Jx, Ju = m.residual_jac(x, u, p, 2)
+    for j in range(m.nx):
+        e = np.zeros(m.nx); e[j] = h
+        col = (m.residual(x + e, u, p, 2) - m.residual(x - e, u, p, 2)) / (2 * h)
+        np.testing.assert_allclose(Jx[:, j], col, rtol=1e-5, atol=1e-5 * max(1, np.max(np.abs(col))))
+    for j in range(m.nu):
+        e = np.zeros(m.nu); e[j] = h
+        col = (m.residual(x, u + e, p, 2) - m.residual(x, u - e, p, 2)) / (2 * h)
+        np.testing.assert_allclose(Ju[:, j], col, rtol=1e-5, atol=1e-5 * max(1, np.max(np.abs(col))))
+
+
+def test_static_input_is_an_equilibrium():
+    """prb.py:243: f_z = m*9.81/force_scaling/nc on every contact gives rddot = 0 (pins gravity sign / scaling)."""
+    for name in ("srbd13", "srbd37"):
+        m = models.make_model(name)
+        x0, us = m.initial_state(), m.static_input()
+        p = m.default_params(5)[0]
+        xn = m.f(x0, us, p)
+        np.testing.assert_allclose(xn[m.RD_], 0.0, atol=1e-12)
+        np.testing.assert_allclose(xn[m.R_], x0[m.R_], atol=1e-12)
+        np.testing.assert_allclose(xn[m.O_], [0, 0, 0, 1], atol=1e-12)
+        # symmetric feet under the CoM: no net torque either
+        np.testing.assert_allclose(xn[m.W_], 0.0, atol=1e-12)
+
+
+def test_layouts_follow_reference_literals():
+    """prb.py:224-246: 37-vector / 24-vector literals; ddp.py:173-177: parameter creation order."""
+    m = models.make_model("srbd37")
+    x0 = m.initial_state()
+    assert x0.shape == (37,) and tuple(x0[3:7]) == (0, 0, 0, 1) and np.all(x0[19:] == 0)
+    np.testing.assert_allclose(x0[7:19], np.asarray(m.cst.feet).reshape(-1))
+    us = m.static_input()
+    assert us.shape == (24,)
+    fz = m.cst.m * 9.81 / 1000.0 / 4
+    np.testing.assert_allclose(us.reshape(4, 6), np.tile([0, 0, 0, 0, 0, fz], (4, 1)))
+    P = m.default_params(20)
+    assert P.shape == (21, 19)
+    np.testing.assert_allclose(P[0], [0, 0, 0, 0, 0, 0, 10, 0, 1, 0, 1, 0, 1, 0, 1, 0, 0, 0, 1])
+    lip = models.make_model("lip30")
+    assert lip.initial_state().shape == (30,) and lip.static_input().shape == (15,)
+    assert lip.default_params(20).shape == (21, 11)
+
+
+def test_hadamard_inertia_quirk_is_reproduced():
+    """prb.py:99 uses CasADi element-wise '*': at identity orientation I_w = diag(I)."""
+    cst = models.RobotConsts()
+    M, _ = models.world_inertia(cst, np.array([0, 0, 0, 1.0]))
+    np.testing.assert_allclose(M, np.diag(np.diag(cst.I)) / 1000.0)
+    cst2 = models.RobotConsts(inertia_mode=1)
+    M2, _ = models.world_inertia(cst2, np.array([0, 0, 0, 1.0]))
+    np.testing.assert_allclose(M2, cst.I / 1000.0)
+
+
+def test_terminal_cost_has_no_constraints_and_node0_no_state_cost():
+    """ddp.py:216-226 (no constraints at N) and prb.py:184-199 (state residuals on nodes 1..ns only)."""
+    m = models.make_model("srbd37")
+    rng = np.random.default_rng(0)
+    x, u, p = _rand_point(m, rng)
+    n_term = m.residual(x, None, p, 20).shape[0]
+    n0 = m.residual(x, u, p, 0).shape[0]
+    nk = m.residual(x, u, p, 5).shape[0]
+    assert n_term == 1 + 4 + 3 + 3 + 4
+    assert n0 == 18 + 4 * 6 + (2 + 2 + 4 * 3)
+    assert nk == n0 + n_term
