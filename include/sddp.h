@@ -1,0 +1,138 @@
+/* sddp.h -- C ABI of the MI355X-native SRBD/LIP DDP engine (libsddp_hip.so).
+ *
+ * This is the drop-in boundary for the per-tick solve of hucebot/srbd_horizon: it replaces the surface of the
+ * external native module `pyddp` that the reference's adapter binds (reference python/ddp.py).  Each entry point
+ * cites the reference call it replaces.  CasADi `Function` lists (f_list, L_list, L_term: ddp.py:83-94) are
+ * replaced by a `model_id` + `sddp_model_consts`, because the models are hand-written analytic HIP code.
+ *
+ * Conventions: plain C, plain pointers and sizes; every function returns an int status (0 = ok, <0 = error,
+ * message via sddp_last_error) and never throws; all arrays are float64, knot-major, C-contiguous:
+ *     x      [B][N+1][nx]      u [B][N][nu]      params [B][N+1][np]      x0 [B][nx]
+ * (the ctypes shim transposes to the reference's [dim, nodes] numpy layout, ddp.py:139,:146).
+ * Host-pointer calls copy through PCIe; the *_device calls take HBM-resident pointers (the bench path).
+ * One HIP stream per handle; a handle is not thread-safe (the reference drives its solver from one thread,
+ * dsrbd_example.py:82-135).
+ */
+#ifndef SDDP_H
+#define SDDP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDDP_ABI_VERSION 1
+
+/* model ids */
+#define SDDP_MODEL_SRBD13 0 /* nx=13 nu=6  np=19 : BASELINE.json metric model (contacts are per-knot parameters) */
+#define SDDP_MODEL_SRBD37 1 /* nx=37 nu=24 np=19 : reference SRBD problem, prb.py:16-246                        */
+#define SDDP_MODEL_LIP30  2 /* nx=30 nu=15 np=11 : reference LIP problem,  prb.py:248-441                       */
+
+/* status codes */
+#define SDDP_OK 0
+#define SDDP_ERR_ARG (-1)
+#define SDDP_ERR_HIP (-2)
+#define SDDP_ERR_MODEL (-3)
+#define SDDP_ERR_NOMEM (-4)
+
+/* replaces pyddp.DdpSolverOptions (fields set at ddp.py:14-35) */
+typedef struct sddp_options {
+    int    max_iters;                   /* ddp.py:17-19  */
+    double alpha_0;                     /* ddp.py:20-22  */
+    double alpha_converge_threshold;    /* ddp.py:23-25  */
+    double line_search_decrease_factor; /* ddp.py:26-28  */
+    double beta;                        /* ddp.py:29-31  */
+    double cost_reduction_ths;          /* ddp.py:32-33  */
+    double mu0;                         /* ddp.py:34-35  */
+    int    initial_rollout;             /* 1: single shooting (x warm start ignored); 0: multiple shooting */
+    double gap_tol;                     /* defect 1-norm below which the gaps count as closed */
+    double mu_min;                      /* regularisation bump floor */
+    double mu_max;                      /* give up above this */
+} sddp_options;
+
+/* replaces what the reference bakes into the CasADi graphs from the URDF and the rosparam server
+ * (prb.py:92-99 mass/inertia, prb.py:130-139 feet/com, prb.py:142-150 and :358-362 gains) */
+typedef struct sddp_model_consts {
+    double m;              /* kg                                   prb.py:92    */
+    double I[9];           /* kg m^2, row major                    prb.py:94-95 */
+    double com[3];         /*                                      prb.py:138   */
+    double feet[12];       /* 4 contact points x 3, row major      prb.py:130-131 */
+    double dt;             /* T/ns                                 prb.py:110   */
+    double force_scaling;  /* 1000                                 prb.py:98    */
+    double r_tracking_gain, rdot_tracking_gain, w_tracking_gain, rel_pos_gain;       /* prb.py:142-147 */
+    double force_switch_weight, min_qddot_gain, min_f_gain, zmp_tracking_gain;       /* prb.py:148-150, :360 */
+    double lip_height;     /* 0.88                                 prb.py:317   */
+    int    inertia_mode;   /* 0: R o I o R^T element-wise (reference-faithful, prb.py:99); 1: R I R^T */
+    double lever_sign;     /* +1: (c - r) x f ; -1: (r - c) x f    */
+} sddp_model_consts;
+
+/* per-instance solve record (what pyddp exposes only as is_converged(), ddp.py:106, plus the tic/toc of
+ * dsrbd_example.py:134-136) */
+typedef struct sddp_stats {
+    double cost;       /* final total cost                                  */
+    double alpha;      /* last accepted (or last tried) step length         */
+    double gap;        /* remaining defect 1-norm                           */
+    double mu;         /* final regularisation                              */
+    double expected;   /* last expected reduction -(dV1+dV2)                */
+    int    iters;      /* accepted iterations                               */
+    int    converged;  /* 1/0                                               */
+    int    status;     /* 0 ok, 1 max_iters, 2 regularisation overflow, 3 non-finite */
+    int    rollouts;   /* forward passes executed                           */
+} sddp_stats;
+
+typedef struct sddp_handle sddp_handle;
+
+int  sddp_abi_version(void);
+int  sddp_model_dims(int model_id, int* nx, int* nu, int* np);
+void sddp_default_options(sddp_options* opts);
+void sddp_default_consts(sddp_model_consts* consts);
+
+/* replaces pyddp.DdpSolver(nx, nu, f_list, L_list, L_term, opts)                        ddp.py:93-94 */
+int  sddp_create(sddp_handle** out, int model_id, int N, int batch,
+                 const sddp_options* opts, const sddp_model_consts* consts);
+void sddp_destroy(sddp_handle* h);
+const char* sddp_last_error(const sddp_handle* h); /* h may be NULL: last create() error */
+int  sddp_set_options(sddp_handle* h, const sddp_options* opts);
+
+/* replaces DdpSolver.set_initial_state(x0)                                              ddp.py:122-123 */
+int  sddp_set_initial_state(sddp_handle* h, const double* x0 /*[B][nx]*/);
+/* replaces DdpSolver.set_x_warmstart(x) / set_u_warmstart(u)                            ddp.py:113-117 */
+int  sddp_set_x_warmstart(sddp_handle* h, const double* x /*[B][N+1][nx]*/);
+int  sddp_set_u_warmstart(sddp_handle* h, const double* u /*[B][N][nu]*/);
+/* replaces x, u = DdpSolver.solve(param_values_list)                                    ddp.py:101 */
+int  sddp_solve(sddp_handle* h, const double* params /*[B][N+1][np]*/,
+                double* x_out /*[B][N+1][nx]*/, double* u_out /*[B][N][nu]*/, sddp_stats* stats /*[B] or NULL*/);
+/* replaces DdpSolver.is_converged()                                                     ddp.py:106 */
+int  sddp_is_converged(sddp_handle* h, int* flags /*[B]*/);
+
+/* ---- HBM-resident path (no PCIe in the call): pointers are DEVICE pointers ------------------------------- */
+int  sddp_set_stream(sddp_handle* h, void* hip_stream);
+int  sddp_set_initial_state_device(sddp_handle* h, const double* d_x0);
+int  sddp_set_x_warmstart_device(sddp_handle* h, const double* d_x);
+int  sddp_set_u_warmstart_device(sddp_handle* h, const double* d_u);
+/* asynchronous on the handle's stream; results stay in the handle's buffers (sddp_device_ptr) */
+int  sddp_solve_device(sddp_handle* h, const double* d_params);
+int  sddp_synchronize(sddp_handle* h);
+/* which: 0 xs [B][N+1][nx], 1 us [B][N][nu], 2 stats [B] (sddp_stats), 3 gains [B][N][nu*(nx+1)] */
+int  sddp_device_ptr(sddp_handle* h, int which, void** ptr, long long* bytes);
+/* average device time (ms) of the last `sddp_solve*` kernel launch measured with HIP events on the handle's stream */
+int  sddp_last_kernel_ms(sddp_handle* h, double* ms);
+int  sddp_enable_timing(sddp_handle* h, int on);
+
+/* ---- building blocks exposed for parity tests (host pointers) ------------------------------------------------
+ * The same device code the fused solve kernel uses, one phase at a time.
+ * sddp_eval_knots: per-knot model evaluation (reference: CasADi evaluation of f_k / L_k and their derivatives
+ * inside pyddp; problem definition prb.py:92-110, :141-204).  nk knots, node index k[i] (k==N: terminal).
+ *   f_out [nk][nx], F_out [nk][nx][nx+nu] (= [fx fu]), H_out [nk][nz][nz] (GN Hessian of L), g_out [nk][nz], L_out [nk] */
+int  sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk, const int* k,
+                     const double* x, const double* u, const double* p,
+                     double* f_out, double* F_out, double* H_out, double* g_out, double* L_out);
+/* one backward sweep on the handle's current trajectory: gains [B][N][nu*(nx+1)] (kff then K row-major),
+ * scal [B][8] = dV1, dV2, G1, G2, ok, mu, qu_inf, Vx0[0] */
+int  sddp_backward(sddp_handle* h, const double* params, double mu, double* gains_out, double* scal_out);
+/* one forward pass at step `alpha` from the handle's trajectory and the gains of the last sddp_backward */
+int  sddp_forward(sddp_handle* h, const double* params, double alpha, double* x_out, double* u_out, double* cost_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDDP_H */

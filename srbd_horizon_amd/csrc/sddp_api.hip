@@ -1,0 +1,456 @@
+// sddp_api.hip -- C ABI (include/sddp.h) over the HIP kernels.  Host side of the drop-in boundary that replaces
+// the `pyddp` surface bound by the reference adapter (python/ddp.py:93-94, :101, :106, :113-123).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sddp.h"
+#include "sddp_kernels.hpp"
+#include "sddp_models.hpp"
+
+using namespace sddp;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Dims {
+    int nx, nu, np, nrec;
+    size_t lds;
+};
+
+bool model_dims(int id, Dims& d) {
+    switch (id) {
+        case SDDP_MODEL_SRBD13: d = {Srbd13::NX, Srbd13::NU, Srbd13::NP, Srbd13::NREC, Lds<Srbd13>::BYTES}; return true;
+        case SDDP_MODEL_SRBD37: d = {Srbd37::NX, Srbd37::NU, Srbd37::NP, Srbd37::NREC, Lds<Srbd37>::BYTES}; return true;
+        case SDDP_MODEL_LIP30: d = {Lip30::NX, Lip30::NU, Lip30::NP, Lip30::NREC, Lds<Lip30>::BYTES}; return true;
+        default: return false;
+    }
+}
+
+}  // namespace
+
+struct sddp_handle {
+    int model_id = 0, N = 0, B = 0;
+    Dims d{};
+    sddp_options opts{};
+    sddp_model_consts consts{};
+    DevConsts dc{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // device buffers
+    double *x0 = nullptr, *P = nullptr, *xs = nullptr, *us = nullptr, *xn = nullptr, *un = nullptr, *dft = nullptr,
+           *gains = nullptr, *rec = nullptr, *scal = nullptr;
+    sddp_stats* stats = nullptr;
+    // timing
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0;
+    std::string err;
+    bool have_x0 = false, have_xws = false, have_uws = false;
+
+    size_t n_x() const { return size_t(B) * (N + 1) * d.nx; }
+    size_t n_u() const { return size_t(B) * N * d.nu; }
+    size_t n_p() const { return size_t(B) * (N + 1) * d.np; }
+    size_t n_g() const { return size_t(B) * N * d.nu * (d.nx + 1); }
+};
+
+namespace {
+
+int fail(sddp_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(h, SDDP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+SolveArgs make_args(sddp_handle* h, const double* d_params) {
+    SolveArgs a;
+    a.c = h->dc; a.o = h->opts; a.N = h->N; a.B = h->B;
+    a.x0 = h->x0; a.P = d_params; a.xs = h->xs; a.us = h->us; a.xn = h->xn; a.un = h->un; a.dft = h->dft;
+    a.gains = h->gains; a.rec = h->rec; a.stats = h->stats; a.scal = h->scal; a.alpha = 0.0; a.mu = 0.0;
+    return a;
+}
+
+template <class M>
+int launch_solve(sddp_handle* h, const SolveArgs& a) {
+    auto kern = solve_kernel<M>;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<M>::BYTES));
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(h->B), dim3(kWave), Lds<M>::BYTES, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    return SDDP_OK;
+}
+template <class M>
+int launch_backward(sddp_handle* h, const SolveArgs& a) {
+    auto kern = backward_kernel<M>;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<M>::BYTES));
+    hipLaunchKernelGGL(kern, dim3(h->B), dim3(kWave), Lds<M>::BYTES, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return SDDP_OK;
+}
+template <class M>
+int launch_forward(sddp_handle* h, const SolveArgs& a) {
+    hipLaunchKernelGGL(forward_kernel<M>, dim3(h->B), dim3(kWave), 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return SDDP_OK;
+}
+
+#define DISPATCH(h, fn, ...)                                                 \
+    switch ((h)->model_id) {                                                 \
+        case SDDP_MODEL_SRBD13: rc = fn<Srbd13>(__VA_ARGS__); break;          \
+        case SDDP_MODEL_SRBD37: rc = fn<Srbd37>(__VA_ARGS__); break;          \
+        case SDDP_MODEL_LIP30: rc = fn<Lip30>(__VA_ARGS__); break;            \
+        default: rc = SDDP_ERR_MODEL;                                         \
+    }
+
+int check_ready(sddp_handle* h) {
+    if (!h) return SDDP_ERR_ARG;
+    if (!h->have_x0) return fail(h, SDDP_ERR_ARG, "sddp_set_initial_state has not been called");
+    if (!h->have_uws) return fail(h, SDDP_ERR_ARG, "sddp_set_u_warmstart has not been called");
+    if (!h->have_xws && !h->opts.initial_rollout)
+        return fail(h, SDDP_ERR_ARG, "sddp_set_x_warmstart has not been called (multiple shooting)");
+    return SDDP_OK;
+}
+
+int validate_options(sddp_handle* h, const sddp_options& o) {
+    if (o.max_iters < 0) return fail(h, SDDP_ERR_ARG, "max_iters < 0");
+    if (!(o.line_search_decrease_factor > 0.0 && o.line_search_decrease_factor < 1.0))
+        return fail(h, SDDP_ERR_ARG, "line_search_decrease_factor must be in (0,1)");
+    if (!(o.alpha_0 > 0.0)) return fail(h, SDDP_ERR_ARG, "alpha_0 must be > 0");
+    if (!(o.alpha_converge_threshold > 0.0)) return fail(h, SDDP_ERR_ARG, "alpha_converge_threshold must be > 0");
+    if (!(o.mu_min > 0.0)) return fail(h, SDDP_ERR_ARG, "mu_min must be > 0");
+    return SDDP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sddp_abi_version(void) { return SDDP_ABI_VERSION; }
+
+int sddp_model_dims(int model_id, int* nx, int* nu, int* np) {
+    Dims d;
+    if (!model_dims(model_id, d)) return SDDP_ERR_MODEL;
+    if (nx) *nx = d.nx;
+    if (nu) *nu = d.nu;
+    if (np) *np = d.np;
+    return SDDP_OK;
+}
+
+void sddp_default_options(sddp_options* o) {
+    if (!o) return;
+    o->max_iters = 100;                      // ddp.py:17
+    o->alpha_0 = 1.0;                        // ddp.py:20
+    o->alpha_converge_threshold = 1e-1;      // ddp.py:23
+    o->line_search_decrease_factor = 0.5;    // ddp.py:26
+    o->beta = 1e-4;                          // ddp.py:29
+    o->cost_reduction_ths = 1e-6;            // engine default (unpinned upstream)
+    o->mu0 = 0.0;                            // engine default (unpinned upstream)
+    o->initial_rollout = 0;
+    o->gap_tol = 1e-9;
+    o->mu_min = 1e-6;
+    o->mu_max = 1e12;
+}
+
+void sddp_default_consts(sddp_model_consts* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->m = 40.0;
+    const double I[9] = {2.0, 0.03, -0.02, 0.03, 1.8, 0.04, -0.02, 0.04, 0.6};
+    std::memcpy(c->I, I, sizeof(I));
+    c->com[0] = 0.0; c->com[1] = 0.0; c->com[2] = 0.88;
+    const double feet[12] = {0.08, 0.1, 0.0, -0.08, 0.1, 0.0, 0.08, -0.1, 0.0, -0.08, -0.1, 0.0};
+    std::memcpy(c->feet, feet, sizeof(feet));
+    c->dt = 0.05;
+    c->force_scaling = 1000.0;
+    c->r_tracking_gain = 1e3; c->rdot_tracking_gain = 1e4; c->w_tracking_gain = 1e4; c->rel_pos_gain = 1e4;
+    c->force_switch_weight = 1e2; c->min_qddot_gain = 1e0; c->min_f_gain = 1e-2; c->zmp_tracking_gain = 1e3;
+    c->lip_height = 0.88;
+    c->inertia_mode = 0;
+    c->lever_sign = 1.0;
+}
+
+const char* sddp_last_error(const sddp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_options* opts, const sddp_model_consts* consts) {
+    if (!out) return fail(nullptr, SDDP_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    Dims d;
+    if (!model_dims(model_id, d)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
+    if (N < 1 || batch < 1) return fail(nullptr, SDDP_ERR_ARG, "N and batch must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, SDDP_ERR_HIP, "no HIP device visible: the SDDP engine has no CPU fallback");
+    sddp_handle* h = new (std::nothrow) sddp_handle();
+    if (!h) return fail(nullptr, SDDP_ERR_NOMEM, "out of host memory");
+    h->model_id = model_id; h->N = N; h->B = batch; h->d = d;
+    if (opts) h->opts = *opts; else sddp_default_options(&h->opts);
+    if (consts) h->consts = *consts; else sddp_default_consts(&h->consts);
+    int rc = validate_options(h, h->opts);
+    if (rc != SDDP_OK) { g_create_error = h->err; delete h; return rc; }
+    h->dc = make_dev_consts(h->consts);
+    auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
+    hipError_t e = hipSuccess;
+    const size_t D = sizeof(double);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    h->own_stream = (e == hipSuccess);
+    if (e == hipSuccess) e = alloc((void**)&h->x0, size_t(batch) * d.nx * D);
+    if (e == hipSuccess) e = alloc((void**)&h->P, h->n_p() * D);
+    if (e == hipSuccess) e = alloc((void**)&h->xs, h->n_x() * D);
+    if (e == hipSuccess) e = alloc((void**)&h->us, h->n_u() * D);
+    if (e == hipSuccess) e = alloc((void**)&h->xn, h->n_x() * D);
+    if (e == hipSuccess) e = alloc((void**)&h->un, h->n_u() * D);
+    if (e == hipSuccess) e = alloc((void**)&h->dft, size_t(batch) * N * d.nx * D);
+    if (e == hipSuccess) e = alloc((void**)&h->gains, h->n_g() * D);
+    if (e == hipSuccess) e = alloc((void**)&h->rec, size_t(batch) * (N + 1) * d.nrec * D);
+    if (e == hipSuccess) e = alloc((void**)&h->scal, size_t(batch) * 8 * D);
+    if (e == hipSuccess) e = alloc((void**)&h->stats, size_t(batch) * sizeof(sddp_stats));
+    if (e == hipSuccess) e = hipMemset(h->stats, 0, size_t(batch) * sizeof(sddp_stats));
+    if (e == hipSuccess) e = hipMemset(h->dft, 0, size_t(batch) * N * d.nx * D);
+    if (e == hipSuccess) e = hipMemset(h->gains, 0, h->n_g() * D);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) {
+        g_create_error = std::string("sddp_create: ") + hipGetErrorString(e);
+        sddp_destroy(h);
+        return SDDP_ERR_HIP;
+    }
+    *out = h;
+    return SDDP_OK;
+}
+
+void sddp_destroy(sddp_handle* h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->dft, h->gains, h->rec, h->scal, h->stats};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int sddp_set_options(sddp_handle* h, const sddp_options* opts) {
+    if (!h || !opts) return SDDP_ERR_ARG;
+    int rc = validate_options(h, *opts);
+    if (rc != SDDP_OK) return rc;
+    h->opts = *opts;
+    return SDDP_OK;
+}
+
+int sddp_set_stream(sddp_handle* h, void* s) {
+    if (!h) return SDDP_ERR_ARG;
+    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    h->stream = reinterpret_cast<hipStream_t>(s);
+    h->own_stream = false;
+    return SDDP_OK;
+}
+
+// ---- host-pointer setters -------------------------------------------------------------------------------------------
+int sddp_set_initial_state(sddp_handle* h, const double* x0) {
+    if (!h || !x0) return SDDP_ERR_ARG;
+    HIP_TRY(h, hipMemcpyAsync(h->x0, x0, size_t(h->B) * h->d.nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_x0 = true;
+    return SDDP_OK;
+}
+int sddp_set_x_warmstart(sddp_handle* h, const double* x) {
+    if (!h || !x) return SDDP_ERR_ARG;
+    HIP_TRY(h, hipMemcpyAsync(h->xs, x, h->n_x() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_xws = true;
+    return SDDP_OK;
+}
+int sddp_set_u_warmstart(sddp_handle* h, const double* u) {
+    if (!h || !u) return SDDP_ERR_ARG;
+    HIP_TRY(h, hipMemcpyAsync(h->us, u, h->n_u() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_uws = true;
+    return SDDP_OK;
+}
+// ---- device-pointer setters -----------------------------------------------------------------------------------------
+int sddp_set_initial_state_device(sddp_handle* h, const double* d) {
+    if (!h || !d) return SDDP_ERR_ARG;
+    HIP_TRY(h, hipMemcpyAsync(h->x0, d, size_t(h->B) * h->d.nx * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->have_x0 = true;
+    return SDDP_OK;
+}
+int sddp_set_x_warmstart_device(sddp_handle* h, const double* d) {
+    if (!h || !d) return SDDP_ERR_ARG;
+    HIP_TRY(h, hipMemcpyAsync(h->xs, d, h->n_x() * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->have_xws = true;
+    return SDDP_OK;
+}
+int sddp_set_u_warmstart_device(sddp_handle* h, const double* d) {
+    if (!h || !d) return SDDP_ERR_ARG;
+    HIP_TRY(h, hipMemcpyAsync(h->us, d, h->n_u() * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->have_uws = true;
+    return SDDP_OK;
+}
+
+int sddp_solve_device(sddp_handle* h, const double* d_params) {
+    int rc = check_ready(h);
+    if (rc != SDDP_OK) return rc;
+    if (!d_params) return fail(h, SDDP_ERR_ARG, "params is NULL");
+    SolveArgs a = make_args(h, d_params);
+    DISPATCH(h, launch_solve, h, a);
+    return rc;
+}
+
+int sddp_synchronize(sddp_handle* h) {
+    if (!h) return SDDP_ERR_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->timing) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_ms = ms;
+    }
+    return SDDP_OK;
+}
+
+int sddp_solve(sddp_handle* h, const double* params, double* x_out, double* u_out, sddp_stats* stats) {
+    int rc = check_ready(h);
+    if (rc != SDDP_OK) return rc;
+    if (!params || !x_out || !u_out) return fail(h, SDDP_ERR_ARG, "NULL argument");
+    HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = sddp_solve_device(h, h->P);
+    if (rc != SDDP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(x_out, h->xs, h->n_x() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(u_out, h->us, h->n_u() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (stats) HIP_TRY(h, hipMemcpyAsync(stats, h->stats, size_t(h->B) * sizeof(sddp_stats), hipMemcpyDeviceToHost, h->stream));
+    rc = sddp_synchronize(h);
+    // the solution is the next warm start unless the caller overrides it (solver object persists across ticks,
+    // dsrbd_example.py:59)
+    h->have_xws = true;
+    return rc;
+}
+
+int sddp_is_converged(sddp_handle* h, int* flags) {
+    if (!h || !flags) return SDDP_ERR_ARG;
+    std::vector<sddp_stats> st(h->B);
+    HIP_TRY(h, hipMemcpyAsync(st.data(), h->stats, size_t(h->B) * sizeof(sddp_stats), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int b = 0; b < h->B; ++b) flags[b] = st[b].converged;
+    return SDDP_OK;
+}
+
+int sddp_device_ptr(sddp_handle* h, int which, void** ptr, long long* bytes) {
+    if (!h || !ptr) return SDDP_ERR_ARG;
+    long long n = 0;
+    switch (which) {
+        case 0: *ptr = h->xs; n = (long long)(h->n_x() * sizeof(double)); break;
+        case 1: *ptr = h->us; n = (long long)(h->n_u() * sizeof(double)); break;
+        case 2: *ptr = h->stats; n = (long long)(size_t(h->B) * sizeof(sddp_stats)); break;
+        case 3: *ptr = h->gains; n = (long long)(h->n_g() * sizeof(double)); break;
+        default: return fail(h, SDDP_ERR_ARG, "unknown buffer id");
+    }
+    if (bytes) *bytes = n;
+    return SDDP_OK;
+}
+
+int sddp_enable_timing(sddp_handle* h, int on) {
+    if (!h) return SDDP_ERR_ARG;
+    h->timing = on != 0;
+    return SDDP_OK;
+}
+int sddp_last_kernel_ms(sddp_handle* h, double* ms) {
+    if (!h || !ms) return SDDP_ERR_ARG;
+    *ms = h->last_ms;
+    return SDDP_OK;
+}
+
+// ---- test building blocks ----------------------------------------------------------------------------------------------
+int sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk, const int* k, const double* x,
+                    const double* u, const double* p, double* f_out, double* F_out, double* H_out, double* g_out, double* L_out) {
+    Dims d;
+    if (!model_dims(model_id, d)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
+    if (nk < 1 || !k || !x || !u || !p) return fail(nullptr, SDDP_ERR_ARG, "bad argument");
+    sddp_model_consts cc;
+    if (consts) cc = *consts; else sddp_default_consts(&cc);
+    const DevConsts dc = make_dev_consts(cc);
+    const int nz = d.nx + d.nu;
+    const size_t D = sizeof(double);
+    int* dk = nullptr;
+    double *dx = nullptr, *du = nullptr, *dp = nullptr, *drec = nullptr, *df = nullptr, *dF = nullptr, *dH = nullptr, *dg = nullptr, *dL = nullptr;
+#define TRY0(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(nullptr, SDDP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+    TRY0(hipMalloc((void**)&dk, nk * sizeof(int)));
+    TRY0(hipMalloc((void**)&dx, size_t(nk) * d.nx * D));
+    TRY0(hipMalloc((void**)&du, size_t(nk) * d.nu * D));
+    TRY0(hipMalloc((void**)&dp, size_t(nk) * d.np * D));
+    TRY0(hipMalloc((void**)&drec, size_t(nk) * d.nrec * D));
+    TRY0(hipMalloc((void**)&df, size_t(nk) * d.nx * D));
+    TRY0(hipMalloc((void**)&dF, size_t(nk) * d.nx * nz * D));
+    TRY0(hipMalloc((void**)&dH, size_t(nk) * nz * nz * D));
+    TRY0(hipMalloc((void**)&dg, size_t(nk) * nz * D));
+    TRY0(hipMalloc((void**)&dL, size_t(nk) * D));
+    TRY0(hipMemcpy(dk, k, nk * sizeof(int), hipMemcpyHostToDevice));
+    TRY0(hipMemcpy(dx, x, size_t(nk) * d.nx * D, hipMemcpyHostToDevice));
+    TRY0(hipMemcpy(du, u, size_t(nk) * d.nu * D, hipMemcpyHostToDevice));
+    TRY0(hipMemcpy(dp, p, size_t(nk) * d.np * D, hipMemcpyHostToDevice));
+    TRY0(hipMemset(drec, 0, size_t(nk) * d.nrec * D));
+    switch (model_id) {
+        case SDDP_MODEL_SRBD13: hipLaunchKernelGGL(eval_knots_kernel<Srbd13>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL); break;
+        case SDDP_MODEL_SRBD37: hipLaunchKernelGGL(eval_knots_kernel<Srbd37>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL); break;
+        case SDDP_MODEL_LIP30: hipLaunchKernelGGL(eval_knots_kernel<Lip30>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL); break;
+    }
+    TRY0(hipGetLastError());
+    TRY0(hipDeviceSynchronize());
+    if (f_out) TRY0(hipMemcpy(f_out, df, size_t(nk) * d.nx * D, hipMemcpyDeviceToHost));
+    if (F_out) TRY0(hipMemcpy(F_out, dF, size_t(nk) * d.nx * nz * D, hipMemcpyDeviceToHost));
+    if (H_out) TRY0(hipMemcpy(H_out, dH, size_t(nk) * nz * nz * D, hipMemcpyDeviceToHost));
+    if (g_out) TRY0(hipMemcpy(g_out, dg, size_t(nk) * nz * D, hipMemcpyDeviceToHost));
+    if (L_out) TRY0(hipMemcpy(L_out, dL, size_t(nk) * D, hipMemcpyDeviceToHost));
+    void* bufs[] = {dk, dx, du, dp, drec, df, dF, dH, dg, dL};
+    for (void* b : bufs) (void)hipFree(b);
+#undef TRY0
+    return SDDP_OK;
+}
+
+int sddp_backward(sddp_handle* h, const double* params, double mu, double* gains_out, double* scal_out) {
+    int rc = check_ready(h);
+    if (rc != SDDP_OK) return rc;
+    if (!params) return fail(h, SDDP_ERR_ARG, "params is NULL");
+    HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    SolveArgs a = make_args(h, h->P);
+    a.mu = mu;
+    DISPATCH(h, launch_backward, h, a);
+    if (rc != SDDP_OK) return rc;
+    if (gains_out) HIP_TRY(h, hipMemcpyAsync(gains_out, h->gains, h->n_g() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (scal_out) HIP_TRY(h, hipMemcpyAsync(scal_out, h->scal, size_t(h->B) * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDDP_OK;
+}
+
+int sddp_forward(sddp_handle* h, const double* params, double alpha, double* x_out, double* u_out, double* cost_out) {
+    int rc = check_ready(h);
+    if (rc != SDDP_OK) return rc;
+    if (!params) return fail(h, SDDP_ERR_ARG, "params is NULL");
+    HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    SolveArgs a = make_args(h, h->P);
+    a.alpha = alpha;
+    DISPATCH(h, launch_forward, h, a);
+    if (rc != SDDP_OK) return rc;
+    if (x_out) HIP_TRY(h, hipMemcpyAsync(x_out, h->xn, h->n_x() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (u_out) HIP_TRY(h, hipMemcpyAsync(u_out, h->un, h->n_u() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (cost_out) {
+        std::vector<double> sc(size_t(h->B) * 8);
+        HIP_TRY(h, hipMemcpy(sc.data(), h->scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int b = 0; b < h->B; ++b) cost_out[b] = sc[size_t(b) * 8];
+    }
+    return SDDP_OK;
+}
+
+}  // extern "C"

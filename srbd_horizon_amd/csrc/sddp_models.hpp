@@ -1,0 +1,810 @@
+// sddp_models.hpp -- hand-written analytic device models for the SRBD / LIP DDP engine (gfx950, fp64).
+//
+// Replaces the CasADi graphs the reference builds in python/prb.py and hands to pyddp through
+// python/ddp.py:179-230 (f_k = explicit Euler of xdot, L_k = sum ||res||^2 + 1e6 sum ||g||^2, L_N).
+//
+// A model provides
+//   * per-lane scalar code (one lane = one knot or one line-search candidate; everything in registers):
+//       step()      x+ = f(x,u,p) and the stage cost L_k(x,u,p) in one pass (they share wdot)
+//       term_cost() L_N(x,p)
+//       derivs()    compact derivative record of one knot: the only non-constant Jacobian blocks
+//                   (A = d wdot / d z, quaternion-rate blocks) and the cost gradient
+//   * wave-cooperative expansion used inside the Riccati sweep (one lane = one tile element):
+//       F_entry(i,j)  element of [fx fu]
+//       H_entry(i,j)  element of the Gauss-Newton Hessian  D(p_k) + 2 g_q A^T A
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sddp.h"
+
+namespace sddp {
+
+constexpr double kGravity = 9.81;          // prb.py:243, prb.py:317
+constexpr double kConstraintWeight = 1e6;  // ddp.py:181
+
+// constants derived on the host from sddp_model_consts, passed to kernels by value (kernarg -> SGPRs)
+struct DevConsts {
+    double dt, inv_ms, Is[9], com_z;
+    double w_rz, w_rd, w_w, w_rel, w_f, w_sw, gq, w_pen, w_zmp, w_rxy, eta2;
+    double d1x, d1y, d2x, d2y;  // rel_pos offsets d1 = p2 - p0, d2 = p3 - p1 (prb.py:153-154)
+    double lever;
+    int inertia_mode;
+};
+
+inline DevConsts make_dev_consts(const sddp_model_consts& c) {
+    DevConsts d;
+    d.dt = c.dt;
+    d.inv_ms = c.force_scaling / c.m;                      // 1 / (m / force_scaling)   prb.py:99
+    for (int i = 0; i < 9; ++i) d.Is[i] = c.I[i] / c.force_scaling;
+    d.com_z = c.com[2];
+    d.w_rz = c.r_tracking_gain;                            // residual sqrt(g)*e -> cost g*e^2 (prb.py:184)
+    d.w_rxy = c.r_tracking_gain;                           // prb.py:391
+    d.w_rd = c.rdot_tracking_gain;                         // prb.py:190
+    d.w_w = c.w_tracking_gain;                             // prb.py:191
+    d.w_rel = c.rel_pos_gain;                              // prb.py:192-199
+    d.w_f = c.force_scaling * c.force_scaling * c.min_f_gain;            // prb.py:202
+    d.w_sw = c.force_scaling * c.force_scaling * c.force_switch_weight;  // prb.py:203-204
+    d.gq = c.min_qddot_gain;                               // prb.py:200
+    d.w_pen = kConstraintWeight;                           // ddp.py:181,:196
+    d.w_zmp = c.zmp_tracking_gain;                         // prb.py:393
+    d.eta2 = kGravity / c.lip_height;                      // prb.py:317
+    d.d1x = c.feet[6] - c.feet[0];
+    d.d1y = c.feet[7] - c.feet[1];
+    d.d2x = c.feet[9] - c.feet[3];
+    d.d2y = c.feet[10] - c.feet[4];
+    d.lever = c.lever_sign;
+    d.inertia_mode = c.inertia_mode;
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small fixed-size helpers (all indices compile-time after unrolling -> registers)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ void matvec3(const double* M, const double* v, double* o) {
+    o[0] = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+    o[1] = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+    o[2] = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+}
+// out = M * skew(v)
+__device__ __forceinline__ void mat_skew3(const double* M, const double* v, double* o) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        o[3 * a + 0] = M[3 * a + 1] * v[2] - M[3 * a + 2] * v[1];
+        o[3 * a + 1] = -M[3 * a + 0] * v[2] + M[3 * a + 2] * v[0];
+        o[3 * a + 2] = M[3 * a + 0] * v[1] - M[3 * a + 1] * v[0];
+    }
+}
+// out = skew(v) * M
+__device__ __forceinline__ void skew_mat3(const double* v, const double* M, double* o) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        o[0 + b] = -v[2] * M[3 + b] + v[1] * M[6 + b];
+        o[3 + b] = v[2] * M[0 + b] - v[0] * M[6 + b];
+        o[6 + b] = -v[1] * M[0 + b] + v[0] * M[3 + b];
+    }
+}
+__device__ __forceinline__ void matmul3(const double* A, const double* B, double* o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+__device__ __forceinline__ void inv3(const double* M, double* o) {
+    const double c00 = M[4] * M[8] - M[5] * M[7];
+    const double c01 = M[5] * M[6] - M[3] * M[8];
+    const double c02 = M[3] * M[7] - M[4] * M[6];
+    const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id;
+    o[1] = (M[2] * M[7] - M[1] * M[8]) * id;
+    o[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    o[3] = c01 * id;
+    o[4] = (M[0] * M[8] - M[2] * M[6]) * id;
+    o[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    o[6] = c02 * id;
+    o[7] = (M[1] * M[6] - M[0] * M[7]) * id;
+    o[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+}
+// Horizon utils.toRot (prb.py:97): xyzw quaternion -> matrix, no normalisation
+__device__ __forceinline__ void quat_to_rot(const double* q, double* R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+template <int A>
+__device__ __forceinline__ void quat_to_rot_d(const double* q, double* D) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    if (A == 0) { D[0] = 0; D[1] = 2 * y; D[2] = 2 * z; D[3] = 2 * y; D[4] = -4 * x; D[5] = -2 * w; D[6] = 2 * z; D[7] = 2 * w; D[8] = -4 * x; }
+    if (A == 1) { D[0] = -4 * y; D[1] = 2 * x; D[2] = 2 * w; D[3] = 2 * x; D[4] = 0; D[5] = 2 * z; D[6] = -2 * w; D[7] = 2 * z; D[8] = -4 * y; }
+    if (A == 2) { D[0] = -4 * z; D[1] = -2 * w; D[2] = 2 * x; D[3] = 2 * w; D[4] = -4 * z; D[5] = 2 * y; D[6] = 2 * x; D[7] = 2 * y; D[8] = 0; }
+    if (A == 3) { D[0] = 0; D[1] = -2 * z; D[2] = 2 * y; D[3] = 2 * z; D[4] = 0; D[5] = -2 * x; D[6] = -2 * y; D[7] = 2 * x; D[8] = 0; }
+}
+// world inertia: prb.py:99 `w_R_b * (I/force_scaling) * w_R_b.T` is ELEMENT-WISE in CasADi (mode 0); mode 1 = R I R^T
+__device__ __forceinline__ void world_inertia(const DevConsts& c, const double* R, double* M) {
+    if (c.inertia_mode == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) M[3 * i + j] = R[3 * i + j] * c.Is[3 * i + j] * R[3 * j + i];
+    } else {
+        double T[9];  // Is R^T
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                T[3 * i + j] = c.Is[3 * i] * R[3 * j] + c.Is[3 * i + 1] * R[3 * j + 1] + c.Is[3 * i + 2] * R[3 * j + 2];
+        matmul3(R, T, M);
+    }
+}
+__device__ __forceinline__ void world_inertia_d(const DevConsts& c, const double* R, const double* dR, double* dM) {
+    if (c.inertia_mode == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                dM[3 * i + j] = c.Is[3 * i + j] * (dR[3 * i + j] * R[3 * j + i] + R[3 * i + j] * dR[3 * j + i]);
+    } else {
+        double T[9], U[9];  // T = Is R^T ; U = dR * T ; dM = U + U^T
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                T[3 * i + j] = c.Is[3 * i] * R[3 * j] + c.Is[3 * i + 1] * R[3 * j + 1] + c.Is[3 * i + 2] * R[3 * j + 2];
+        matmul3(dR, T, U);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dM[3 * i + j] = U[3 * i + j] + U[3 * j + i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SRBD family.  CS=false, NC=2: srbd13 (metric model, contacts are parameters);  CS=true, NC=4: srbd37
+// (reference problem, contacts are states -- prb.py:32-68).
+// ---------------------------------------------------------------------------------------------------------
+template <int NC_, bool CS_>
+struct SrbdModel {
+    static constexpr int NC = NC_;
+    static constexpr bool CS = CS_;
+    static constexpr int NX = CS ? 13 + 6 * NC : 13;
+    static constexpr int NU = CS ? 6 * NC : 3 * NC;
+    static constexpr int NZ = NX + NU;
+    static constexpr int NP = 19;
+    static_assert((CS && NC == 4) || (!CS && NC == 2), "parameter layout is fixed to np=19");
+    // state offsets (prb.py:32-59 creation order)
+    static constexpr int XR = 0, XO = 3, XC = 7, XRD = CS ? 7 + 3 * NC : 7, XW = XRD + 3, XCD = XW + 3;
+    // compact columns of A = d wdot / d z : r(0..2) o(3..6) w(7..9) [c(3NC)] f(3NC)
+    static constexpr int AC = 10, AF = 10 + (CS ? 3 * NC : 0), NA = AF + 3 * NC;
+    // derivative record of one knot
+    static constexpr int REC_A = 0, REC_JO = 3 * NA, REC_JW = REC_JO + 16, REC_G = REC_JW + 12, NREC = REC_G + NZ;
+
+    __device__ __forceinline__ static int uf(int i) { return CS ? 6 * i + 3 : 3 * i; }  // prb.py:66-68 interleaved
+    // parameter layouts: srbd37 = creation order; srbd13 = App. A.7
+    __device__ __forceinline__ static double p_rdref(const double* p, int a) { return p[a]; }
+    __device__ __forceinline__ static double p_wref(const double* p, int a) { return p[3 + a]; }
+    __device__ __forceinline__ static double p_otg(const double* p) { return p[6]; }
+    __device__ __forceinline__ static double p_oref(const double* p, int a) { return CS ? p[15 + a] : p[7 + a]; }
+    __device__ __forceinline__ static double p_sw(const double* p, int i) { return CS ? p[8 + 2 * i] : p[17 + i]; }
+    __device__ __forceinline__ static double p_cref(const double* p, int i) { return p[7 + 2 * i]; }
+
+    struct Core {
+        double Mi[9], M[9], R[9], Mw[3], wdot[3], rddot[3];
+    };
+
+    // rddot, wdot (Horizon kin_dyn.fSRBD, prb.py:99; App. A.3)
+    __device__ __forceinline__ static void core(const DevConsts& c, const double* r, const double* o, const double* w,
+                                                const double (*cp)[3], const double (*f)[3], Core& k) {
+        quat_to_rot(o, k.R);
+        world_inertia(c, k.R, k.M);
+        inv3(k.M, k.Mi);
+        matvec3(k.M, w, k.Mw);
+        double tau[3] = {0, 0, 0}, fs[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            double l[3] = {cp[i][0] - r[0], cp[i][1] - r[1], cp[i][2] - r[2]}, t[3];
+            cross3(l, f[i], t);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { tau[a] += c.lever * t[a]; fs[a] += f[i][a]; }
+        }
+        double g[3];
+        cross3(w, k.Mw, g);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) tau[a] -= g[a];
+        matvec3(k.Mi, tau, k.wdot);
+        k.rddot[0] = fs[0] * c.inv_ms;
+        k.rddot[1] = fs[1] * c.inv_ms;
+        k.rddot[2] = fs[2] * c.inv_ms - kGravity;
+    }
+
+    __device__ __forceinline__ static void load_contacts(const double* x, const double* u, const double* p,
+                                                         double (*cp)[3], double (*f)[3]) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                cp[i][a] = CS ? x[XC + 3 * i + a] : p[11 + 3 * i + a];
+                f[i][a] = u[uf(i) + a];
+            }
+    }
+
+    // cost of the state residuals (nodes 1..ns, prb.py:184-199)
+    __device__ __forceinline__ static double state_cost(const DevConsts& c, const double* x, const double* p) {
+        double L = 0;
+        const double ez = x[XR + 2] - c.com_z;
+        L += c.w_rz * ez * ez;
+        const double* o = x + XO;
+        const double qx = p_oref(p, 0), qy = p_oref(p, 1), qz = p_oref(p, 2), qw = p_oref(p, 3);
+        const double e0 = o[3] * qx + qw * o[0] + (o[1] * qz - o[2] * qy);
+        const double e1 = o[3] * qy + qw * o[1] + (o[2] * qx - o[0] * qz);
+        const double e2 = o[3] * qz + qw * o[2] + (o[0] * qy - o[1] * qx);
+        const double e3 = o[3] * qw - (o[0] * qx + o[1] * qy + o[2] * qz) - 1.0;
+        const double otg = p_otg(p);
+        L += otg * otg * (e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double ed = x[XRD + a] - p_rdref(p, a), ew = x[XW + a] - p_wref(p, a);
+            L += c.w_rd * ed * ed + c.w_w * ew * ew;
+        }
+        if (CS) {
+            const double* c0 = x + XC; const double* c1 = x + XC + 3; const double* c2 = x + XC + 6; const double* c3 = x + XC + 9;
+            const double r1y = -c0[1] + c2[1] - c.d1y, r1x = -c0[0] + c2[0] - c.d1x;
+            const double r2y = -c1[1] + c3[1] - c.d2y, r2x = -c1[0] + c3[0] - c.d2x;
+            L += c.w_rel * (r1y * r1y + r1x * r1x + r2y * r2y + r2x * r2x);
+        }
+        return L;
+    }
+
+    // cost of the input residuals + penalties given rddot/wdot (nodes 0..ns-1, prb.py:200-204, :166-181)
+    __device__ __forceinline__ static double input_cost(const DevConsts& c, const double* x, const double* u, const double* p,
+                                                        const double (*f)[3], const Core& k) {
+        double L = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) L += c.gq * (k.rddot[a] * k.rddot[a] + k.wdot[a] * k.wdot[a]);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const double s1 = 1.0 - p_sw(p, i);
+            const double wf = c.w_f + c.w_sw * s1 * s1;
+            L += wf * (f[i][0] * f[i][0] + f[i][1] * f[i][1] + f[i][2] * f[i][2]);
+        }
+        if (CS) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const double* cdd = u + 6 * i;
+                L += c.gq * (cdd[0] * cdd[0] + cdd[1] * cdd[1] + cdd[2] * cdd[2]);
+                const double ez = x[XC + 3 * i + 2] - p_cref(p, i);
+                const double sw = p_sw(p, i);
+                const double vx = sw * x[XCD + 3 * i], vy = sw * x[XCD + 3 * i + 1];
+                L += c.w_pen * (ez * ez + vx * vx + vy * vy);
+            }
+#pragma unroll
+            for (int b = 0; b < NC; b += 2) {
+                const double ex = x[XCD + 3 * b] - x[XCD + 3 * b + 3], ey = x[XCD + 3 * b + 1] - x[XCD + 3 * b + 4];
+                L += c.w_pen * (ex * ex + ey * ey);
+            }
+        }
+        return L;
+    }
+
+    // x+ = x + dt*xdot (explicit Euler, ddp.py:228-230) and L_k(x,u,p) (ddp.py:179-214) in one pass
+    __device__ __forceinline__ static double step(const DevConsts& c, const double* x, const double* u, const double* p,
+                                                  int k, double* xn) {
+        double cp[NC][3], f[NC][3];
+        load_contacts(x, u, p, cp, f);
+        Core q;
+        const double* r = x + XR; const double* o = x + XO; const double* w = x + XW;
+        core(c, r, o, w, cp, f, q);
+        double L = input_cost(c, x, u, p, f, q);
+        if (k >= 1) L += state_cost(c, x, p);
+        const double dt = c.dt;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            xn[XR + a] = x[XR + a] + dt * x[XRD + a];
+            xn[XRD + a] = x[XRD + a] + dt * q.rddot[a];
+            xn[XW + a] = x[XW + a] + dt * q.wdot[a];
+        }
+        // odot = 1/2 [w;0] (x) o  (LOCAL_WORLD_ALIGNED, prb.py:107-108)
+        double wxo[3];
+        cross3(w, o, wxo);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) xn[XO + a] = o[a] + dt * 0.5 * (o[3] * w[a] + wxo[a]);
+        xn[XO + 3] = o[3] - dt * 0.5 * (w[0] * o[0] + w[1] * o[1] + w[2] * o[2]);
+        if (CS) {
+#pragma unroll
+            for (int i = 0; i < 3 * NC; ++i) {
+                xn[XC + i] = x[XC + i] + dt * x[XCD + i];
+                xn[XCD + i] = x[XCD + i] + dt * u[6 * (i / 3) + (i % 3)];
+            }
+        }
+        return L;
+    }
+
+    __device__ __forceinline__ static double term_cost(const DevConsts& c, const double* x, const double* p) {
+        return state_cost(c, x, p);  // ddp.py:216-226: residuals only, no constraints
+    }
+
+    // compact derivative record of knot k (k == N: terminal -> gradient only)
+    __device__ __forceinline__ static void derivs(const DevConsts& c, const double* x, const double* u, const double* p,
+                                                  int k, int N, double* rec) {
+        double g[NZ];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) g[i] = 0.0;
+        const double* r = x + XR; const double* o = x + XO; const double* w = x + XW;
+        if (k >= 1) {  // state residual gradients
+            g[XR + 2] += 2 * c.w_rz * (x[XR + 2] - c.com_z);
+            const double qv[3] = {p_oref(p, 0), p_oref(p, 1), p_oref(p, 2)};
+            const double qw = p_oref(p, 3);
+            double oxq[3];
+            cross3(o, qv, oxq);
+            double ev[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ev[a] = o[3] * qv[a] + qw * o[a] + oxq[a];
+            const double ew = o[3] * qw - (o[0] * qv[0] + o[1] * qv[1] + o[2] * qv[2]) - 1.0;
+            const double otg = p_otg(p);
+            const double s2 = 2 * otg * otg;
+            double qxe[3];
+            cross3(qv, ev, qxe);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) g[XO + a] += s2 * (qw * ev[a] + qxe[a] - qv[a] * ew);
+            g[XO + 3] += s2 * (qv[0] * ev[0] + qv[1] * ev[1] + qv[2] * ev[2] + qw * ew);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                g[XRD + a] += 2 * c.w_rd * (x[XRD + a] - p_rdref(p, a));
+                g[XW + a] += 2 * c.w_w * (x[XW + a] - p_wref(p, a));
+            }
+            if (CS) {
+                const double r1y = -x[XC + 1] + x[XC + 7] - c.d1y, r1x = -x[XC + 0] + x[XC + 6] - c.d1x;
+                const double r2y = -x[XC + 4] + x[XC + 10] - c.d2y, r2x = -x[XC + 3] + x[XC + 9] - c.d2x;
+                const double s = 2 * c.w_rel;
+                g[XC + 1] -= s * r1y; g[XC + 7] += s * r1y; g[XC + 0] -= s * r1x; g[XC + 6] += s * r1x;
+                g[XC + 4] -= s * r2y; g[XC + 10] += s * r2y; g[XC + 3] -= s * r2x; g[XC + 9] += s * r2x;
+            }
+        }
+        if (k < N) {
+            double cp[NC][3], f[NC][3];
+            load_contacts(x, u, p, cp, f);
+            Core q;
+            core(c, r, o, w, cp, f, q);
+            double A[3][NA];
+            // d wdot / d r = Mi * (s * skew(sum f))
+            {
+                double sf[3] = {0, 0, 0}, T[9];
+#pragma unroll
+                for (int i = 0; i < NC; ++i)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) sf[a] += c.lever * f[i][a];
+                mat_skew3(q.Mi, sf, T);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) A[a][b] = T[3 * a + b];
+            }
+            // d wdot / d w = Mi * (skew(M w) - skew(w) M)
+            {
+                double T[9], U[9], V[9];
+                skew_mat3(w, q.M, T);
+                const double mw[3] = {q.Mw[0], q.Mw[1], q.Mw[2]};
+                U[0] = 0 - T[0]; U[1] = -mw[2] - T[1]; U[2] = mw[1] - T[2];
+                U[3] = mw[2] - T[3]; U[4] = 0 - T[4]; U[5] = -mw[0] - T[5];
+                U[6] = -mw[1] - T[6]; U[7] = mw[0] - T[7]; U[8] = 0 - T[8];
+                matmul3(q.Mi, U, V);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) A[a][7 + b] = V[3 * a + b];
+            }
+            // d wdot / d o_a = -Mi (dM_a wdot + w x (dM_a w))
+            {
+                double col[4][3];
+                dwdot_do<0>(c, o, w, q, col[0]);
+                dwdot_do<1>(c, o, w, q, col[1]);
+                dwdot_do<2>(c, o, w, q, col[2]);
+                dwdot_do<3>(c, o, w, q, col[3]);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) A[a][3 + b] = col[b][a];
+            }
+            // d wdot / d c_i = Mi * (-s skew(f_i)) ; d wdot / d f_i = Mi * (s skew(c_i - r))
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                double T[9];
+                const double l[3] = {c.lever * (cp[i][0] - r[0]), c.lever * (cp[i][1] - r[1]), c.lever * (cp[i][2] - r[2])};
+                mat_skew3(q.Mi, l, T);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) A[a][AF + 3 * i + b] = T[3 * a + b];
+                if (CS) {
+                    const double mf[3] = {-c.lever * f[i][0], -c.lever * f[i][1], -c.lever * f[i][2]};
+                    mat_skew3(q.Mi, mf, T);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) A[a][AC + 3 * i + b] = T[3 * a + b];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int j = 0; j < NA; ++j) rec[REC_A + a * NA + j] = A[a][j];
+            // quaternion-rate blocks: d odot / d o (4x4), d odot / d w (4x3)
+            {
+                double Jo[16], Jw[12];
+                Jo[0] = 0; Jo[1] = -0.5 * w[2]; Jo[2] = 0.5 * w[1]; Jo[3] = 0.5 * w[0];
+                Jo[4] = 0.5 * w[2]; Jo[5] = 0; Jo[6] = -0.5 * w[0]; Jo[7] = 0.5 * w[1];
+                Jo[8] = -0.5 * w[1]; Jo[9] = 0.5 * w[0]; Jo[10] = 0; Jo[11] = 0.5 * w[2];
+                Jo[12] = -0.5 * w[0]; Jo[13] = -0.5 * w[1]; Jo[14] = -0.5 * w[2]; Jo[15] = 0;
+                // 1/2 (o_w I - skew(o_v)) ; last row -1/2 o_v
+                Jw[0] = 0.5 * o[3]; Jw[1] = 0.5 * o[2]; Jw[2] = -0.5 * o[1];
+                Jw[3] = -0.5 * o[2]; Jw[4] = 0.5 * o[3]; Jw[5] = 0.5 * o[0];
+                Jw[6] = 0.5 * o[1]; Jw[7] = -0.5 * o[0]; Jw[8] = 0.5 * o[3];
+                Jw[9] = -0.5 * o[0]; Jw[10] = -0.5 * o[1]; Jw[11] = -0.5 * o[2];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rec[REC_JO + i] = Jo[i];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) rec[REC_JW + i] = Jw[i];
+            }
+            // gradient of the input residuals: min_qddot rows [rddot; wdot; cddot], min_f, f_active, penalties
+            const double s = 2 * c.gq;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const double v = s * (A[0][j] * q.wdot[0] + A[1][j] * q.wdot[1] + A[2][j] * q.wdot[2]);
+                g[zcol(j)] += v;
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const double s1 = 1.0 - p_sw(p, i);
+                const double wf = 2 * (c.w_f + c.w_sw * s1 * s1);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) g[NX + uf(i) + a] += s * q.rddot[a] * c.inv_ms + wf * f[i][a];
+            }
+            if (CS) {
+                const double sp = 2 * c.w_pen;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) g[NX + 6 * i + a] += s * u[6 * i + a];
+                    g[XC + 3 * i + 2] += sp * (x[XC + 3 * i + 2] - p_cref(p, i));
+                    const double sw = p_sw(p, i);
+                    g[XCD + 3 * i] += sp * sw * sw * x[XCD + 3 * i];
+                    g[XCD + 3 * i + 1] += sp * sw * sw * x[XCD + 3 * i + 1];
+                }
+#pragma unroll
+                for (int b = 0; b < NC; b += 2) {
+                    const double ex = x[XCD + 3 * b] - x[XCD + 3 * b + 3], ey = x[XCD + 3 * b + 1] - x[XCD + 3 * b + 4];
+                    g[XCD + 3 * b] += sp * ex; g[XCD + 3 * b + 3] -= sp * ex;
+                    g[XCD + 3 * b + 1] += sp * ey; g[XCD + 3 * b + 4] -= sp * ey;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) rec[REC_G + i] = g[i];
+    }
+
+    template <int QA>
+    __device__ __forceinline__ static void dwdot_do(const DevConsts& c, const double* o, const double* w, const Core& q,
+                                                    double* out) {
+        double dR[9], dM[9], a[3], b[3], cr[3];
+        quat_to_rot_d<QA>(o, dR);
+        world_inertia_d(c, q.R, dR, dM);
+        matvec3(dM, q.wdot, a);
+        matvec3(dM, w, b);
+        cross3(w, b, cr);
+        const double t[3] = {-(a[0] + cr[0]), -(a[1] + cr[1]), -(a[2] + cr[2])};
+        matvec3(q.Mi, t, out);
+    }
+
+    // z index of compact A column j (compile-time after unrolling)
+    __device__ __forceinline__ static constexpr int zcol(int j) {
+        return j < 7 ? j : (j < 10 ? XW + (j - 7) : (CS && j < AF ? XC + (j - AC) : NX + (CS ? 6 * ((j - AF) / 3) + 3 + (j - AF) % 3 : (j - AF))));
+    }
+    // compact A column of z index j, or -1
+    __device__ __forceinline__ static int acol(int j) {
+        if (j < 7) return j;
+        if (CS && j < XRD) return AC + (j - XC);
+        if (j < XW) return -1;
+        if (j < XW + 3) return 7 + (j - XW);
+        if (j < NX) return -1;
+        const int uj = j - NX;
+        if (CS) {
+            const int i = uj / 6, a = uj % 6;
+            return a >= 3 ? AF + 3 * i + (a - 3) : -1;
+        }
+        return AF + uj;
+    }
+
+    // variable class / contact / axis of z index j
+    enum { V_R = 0, V_O, V_C, V_RD, V_W, V_CD, V_CDD, V_F };
+    __device__ __forceinline__ static void decode(int j, int& cls, int& ci, int& ax) {
+        ci = 0;
+        if (j < 3) { cls = V_R; ax = j; return; }
+        if (j < 7) { cls = V_O; ax = j - 3; return; }
+        if (CS && j < XRD) { cls = V_C; ci = (j - XC) / 3; ax = (j - XC) % 3; return; }
+        if (j < XW) { cls = V_RD; ax = j - XRD; return; }
+        if (j < XW + 3) { cls = V_W; ax = j - XW; return; }
+        if (j < NX) { cls = V_CD; ci = (j - XCD) / 3; ax = (j - XCD) % 3; return; }
+        const int uj = j - NX;
+        if (CS) {
+            ci = uj / 6;
+            const int a = uj % 6;
+            if (a < 3) { cls = V_CDD; ax = a; } else { cls = V_F; ax = a - 3; }
+            return;
+        }
+        cls = V_F; ci = uj / 3; ax = uj % 3;
+    }
+
+    // element (i,j) of [fx fu] = [I 0] + dt * d xdot / d z   (rec: this knot's record)
+    __device__ __forceinline__ static double F_entry(const DevConsts& c, const double* rec, int i, int j) {
+        int ci, cli, ai, cj, clj, aj;
+        decode(i, cli, ci, ai);
+        decode(j, clj, cj, aj);
+        double s = 0.0;
+        switch (cli) {
+            case V_R: s = (clj == V_RD && aj == ai) ? 1.0 : 0.0; break;
+            case V_O:
+                if (clj == V_O) s = rec[REC_JO + 4 * ai + aj];
+                else if (clj == V_W) s = rec[REC_JW + 3 * ai + aj];
+                break;
+            case V_C: s = (clj == V_CD && cj == ci && aj == ai) ? 1.0 : 0.0; break;
+            case V_RD: s = (clj == V_F && aj == ai) ? c.inv_ms : 0.0; break;
+            case V_W: { const int a = acol(j); s = a >= 0 ? rec[REC_A + ai * NA + a] : 0.0; } break;
+            case V_CD: s = (clj == V_CDD && cj == ci && aj == ai) ? 1.0 : 0.0; break;
+            default: break;
+        }
+        return (i == j ? 1.0 : 0.0) + c.dt * s;
+    }
+
+    // element (i,j) of the Gauss-Newton Hessian of L_k (k<N) or L_N (k==N)
+    __device__ __forceinline__ static double H_entry(const DevConsts& c, const double* rec, const double* p, int k, int N,
+                                                     int i, int j) {
+        int ci, cli, ai, cj, clj, aj;
+        decode(i, cli, ci, ai);
+        decode(j, clj, cj, aj);
+        const bool state = k >= 1, stage = k < N;
+        double v = 0.0;
+        if (cli == clj && ai == aj) {
+            switch (cli) {
+                case V_R: if (state && ai == 2) v = 2 * c.w_rz; break;
+                case V_O: if (state) {
+                    const double otg = p_otg(p);
+                    const double n2 = p_oref(p, 0) * p_oref(p, 0) + p_oref(p, 1) * p_oref(p, 1) + p_oref(p, 2) * p_oref(p, 2) + p_oref(p, 3) * p_oref(p, 3);
+                    v = 2 * otg * otg * n2;
+                } break;
+                case V_RD: if (state) v = 2 * c.w_rd; break;
+                case V_W: if (state) v = 2 * c.w_w; break;
+                case V_C:
+                    if (state && ai < 2) { if (ci == cj) v += 2 * c.w_rel; else if (ci + 2 == cj || cj + 2 == ci) v -= 2 * c.w_rel; }
+                    if (stage && ci == cj && ai == 2) v += 2 * c.w_pen;
+                    break;
+                case V_CD:
+                    if (stage && ai < 2) {
+                        if (ci == cj) { const double sw = p_sw(p, ci); v = 2 * c.w_pen * (1.0 + sw * sw); }
+                        else if (ci / 2 == cj / 2) v = -2 * c.w_pen;
+                    }
+                    break;
+                case V_CDD: if (stage && ci == cj) v = 2 * c.gq; break;
+                case V_F:
+                    if (stage) {
+                        v = 2 * c.gq * c.inv_ms * c.inv_ms;
+                        if (ci == cj) { const double s1 = 1.0 - p_sw(p, ci); v += 2 * (c.w_f + c.w_sw * s1 * s1); }
+                    }
+                    break;
+                default: break;
+            }
+        }
+        if (stage) {
+            const int a = acol(i), b = acol(j);
+            if (a >= 0 && b >= 0)
+                v += 2 * c.gq * (rec[REC_A + a] * rec[REC_A + b] + rec[REC_A + NA + a] * rec[REC_A + NA + b] +
+                                 rec[REC_A + 2 * NA + a] * rec[REC_A + 2 * NA + b]);
+        }
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// LIP (prb.py:248-441): x = r | c0..3 | rdot | cdot0..3 (30), u = z | cddot0..3 (15), p = rdot_ref | (c_ref_i, sw_i)x4.
+// Linear dynamics + quadratic cost: F and H are constant in (x,u); the record is the gradient only.
+// ---------------------------------------------------------------------------------------------------------
+struct LipModel {
+    static constexpr int NC = 4;
+    static constexpr int NX = 30, NU = 15, NZ = 45, NP = 11;
+    static constexpr int XR = 0, XC = 3, XRD = 15, XCD = 18;
+    static constexpr int REC_G = 0, NREC = NZ;
+    __device__ __forceinline__ static double p_cref(const double* p, int i) { return p[3 + 2 * i]; }
+    __device__ __forceinline__ static double p_sw(const double* p, int i) { return p[4 + 2 * i]; }
+
+    __device__ __forceinline__ static double state_cost(const DevConsts& c, const double* x, const double* p) {
+        const double ez = x[2] - c.com_z;
+        double L = c.w_rz * ez * ez;                                              // rz_tracking  prb.py:390
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const double m = 0.25 * (x[XC + a] + x[XC + 3 + a] + x[XC + 6 + a] + x[XC + 9 + a]);
+            const double e = x[a] - m;
+            L += c.w_rxy * e * e;                                                 // rxy_tracking prb.py:391
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const double e = x[XRD + a] - p[a]; L += c.w_rd * e * e; }   // prb.py:392
+        const double r1y = -x[XC + 1] + x[XC + 7] - c.d1y, r1x = -x[XC + 0] + x[XC + 6] - c.d1x;
+        const double r2y = -x[XC + 4] + x[XC + 10] - c.d2y, r2x = -x[XC + 3] + x[XC + 9] - c.d2x;
+        L += c.w_rel * (r1y * r1y + r1x * r1x + r2y * r2y + r2x * r2x);           // prb.py:394-401
+        return L;
+    }
+
+    __device__ __forceinline__ static double step(const DevConsts& c, const double* x, const double* u, const double* p,
+                                                  int k, double* xn) {
+        double L = 0, rddot[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            rddot[a] = c.eta2 * (x[a] - u[a]) - (a == 2 ? kGravity : 0.0);        // prb.py:317-319
+            const double m = 0.25 * (x[XC + a] + x[XC + 3 + a] + x[XC + 6 + a] + x[XC + 9 + a]);
+            const double e = u[a] - m;
+            L += c.w_zmp * e * e + c.gq * rddot[a] * rddot[a];                    // prb.py:393, :402
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) L += c.gq * u[3 + i] * u[3 + i];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {                                            // penalties prb.py:379-387
+            const double ez = x[XC + 3 * i + 2] - p_cref(p, i), sw = p_sw(p, i);
+            const double vx = sw * x[XCD + 3 * i], vy = sw * x[XCD + 3 * i + 1];
+            L += c.w_pen * (ez * ez + vx * vx + vy * vy);
+        }
+#pragma unroll
+        for (int b = 0; b < NC; b += 2) {
+            const double ex = x[XCD + 3 * b] - x[XCD + 3 * b + 3], ey = x[XCD + 3 * b + 1] - x[XCD + 3 * b + 4];
+            L += c.w_pen * (ex * ex + ey * ey);
+        }
+        if (k >= 1) L += state_cost(c, x, p);
+        const double dt = c.dt;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) xn[i] = x[i] + dt * x[15 + i];               // q += dt qdot  prb.py:323-328
+#pragma unroll
+        for (int a = 0; a < 3; ++a) xn[XRD + a] = x[XRD + a] + dt * rddot[a];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) xn[XCD + i] = x[XCD + i] + dt * u[3 + i];
+        return L;
+    }
+
+    __device__ __forceinline__ static double term_cost(const DevConsts& c, const double* x, const double* p) {
+        return state_cost(c, x, p);
+    }
+
+    __device__ __forceinline__ static void derivs(const DevConsts& c, const double* x, const double* u, const double* p,
+                                                  int k, int N, double* rec) {
+        double g[NZ];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) g[i] = 0.0;
+        if (k >= 1) {
+            g[2] += 2 * c.w_rz * (x[2] - c.com_z);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const double m = 0.25 * (x[XC + a] + x[XC + 3 + a] + x[XC + 6 + a] + x[XC + 9 + a]);
+                const double e = 2 * c.w_rxy * (x[a] - m);
+                g[a] += e;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) g[XC + 3 * i + a] -= 0.25 * e;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) g[XRD + a] += 2 * c.w_rd * (x[XRD + a] - p[a]);
+            const double r1y = -x[XC + 1] + x[XC + 7] - c.d1y, r1x = -x[XC + 0] + x[XC + 6] - c.d1x;
+            const double r2y = -x[XC + 4] + x[XC + 10] - c.d2y, r2x = -x[XC + 3] + x[XC + 9] - c.d2x;
+            const double s = 2 * c.w_rel;
+            g[XC + 1] -= s * r1y; g[XC + 7] += s * r1y; g[XC + 0] -= s * r1x; g[XC + 6] += s * r1x;
+            g[XC + 4] -= s * r2y; g[XC + 10] += s * r2y; g[XC + 3] -= s * r2x; g[XC + 9] += s * r2x;
+        }
+        if (k < N) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double m = 0.25 * (x[XC + a] + x[XC + 3 + a] + x[XC + 6 + a] + x[XC + 9 + a]);
+                const double e = 2 * c.w_zmp * (u[a] - m);
+                g[NX + a] += e;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) g[XC + 3 * i + a] -= 0.25 * e;
+                const double rdd = c.eta2 * (x[a] - u[a]) - (a == 2 ? kGravity : 0.0);
+                const double t = 2 * c.gq * c.eta2 * rdd;
+                g[a] += t;
+                g[NX + a] -= t;
+            }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) g[NX + 3 + i] += 2 * c.gq * u[3 + i];
+            const double sp = 2 * c.w_pen;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                g[XC + 3 * i + 2] += sp * (x[XC + 3 * i + 2] - p_cref(p, i));
+                const double sw = p_sw(p, i);
+                g[XCD + 3 * i] += sp * sw * sw * x[XCD + 3 * i];
+                g[XCD + 3 * i + 1] += sp * sw * sw * x[XCD + 3 * i + 1];
+            }
+#pragma unroll
+            for (int b = 0; b < NC; b += 2) {
+                const double ex = x[XCD + 3 * b] - x[XCD + 3 * b + 3], ey = x[XCD + 3 * b + 1] - x[XCD + 3 * b + 4];
+                g[XCD + 3 * b] += sp * ex; g[XCD + 3 * b + 3] -= sp * ex;
+                g[XCD + 3 * b + 1] += sp * ey; g[XCD + 3 * b + 4] -= sp * ey;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) rec[REC_G + i] = g[i];
+    }
+
+    enum { V_R = 0, V_C, V_RD, V_CD, V_Z, V_CDD };
+    __device__ __forceinline__ static void decode(int j, int& cls, int& ci, int& ax) {
+        ci = 0;
+        if (j < 3) { cls = V_R; ax = j; return; }
+        if (j < 15) { cls = V_C; ci = (j - 3) / 3; ax = (j - 3) % 3; return; }
+        if (j < 18) { cls = V_RD; ax = j - 15; return; }
+        if (j < 30) { cls = V_CD; ci = (j - 18) / 3; ax = (j - 18) % 3; return; }
+        if (j < 33) { cls = V_Z; ax = j - 30; return; }
+        cls = V_CDD; ci = (j - 33) / 3; ax = (j - 33) % 3;
+    }
+
+    __device__ __forceinline__ static double F_entry(const DevConsts& c, const double*, int i, int j) {
+        int ci, cli, ai, cj, clj, aj;
+        decode(i, cli, ci, ai);
+        decode(j, clj, cj, aj);
+        double s = 0.0;
+        if (ai == aj) {
+            switch (cli) {
+                case V_R: s = clj == V_RD ? 1.0 : 0.0; break;
+                case V_C: s = (clj == V_CD && ci == cj) ? 1.0 : 0.0; break;
+                case V_RD: s = clj == V_R ? c.eta2 : (clj == V_Z ? -c.eta2 : 0.0); break;
+                case V_CD: s = (clj == V_CDD && ci == cj) ? 1.0 : 0.0; break;
+                default: break;
+            }
+        }
+        return (i == j ? 1.0 : 0.0) + c.dt * s;
+    }
+
+    __device__ __forceinline__ static double H_entry(const DevConsts& c, const double*, const double* p, int k, int N, int i, int j) {
+        int ci, cli, ai, cj, clj, aj;
+        decode(i, cli, ci, ai);
+        decode(j, clj, cj, aj);
+        if (ai != aj) return 0.0;
+        const bool state = k >= 1, stage = k < N;
+        if (cli > clj) { int t = cli; cli = clj; clj = t; t = ci; ci = cj; cj = t; }
+        const double e4 = 2 * c.gq * c.eta2 * c.eta2;
+        double v = 0.0;
+        if (cli == V_R && clj == V_R) {
+            if (state) v += ai == 2 ? 2 * c.w_rz : 2 * c.w_rxy;
+            if (stage) v += e4;
+        } else if (cli == V_R && clj == V_C) {
+            if (state && ai < 2) v = -0.5 * c.w_rxy;
+        } else if (cli == V_R && clj == V_Z) {
+            if (stage) v = -e4;
+        } else if (cli == V_C && clj == V_C) {
+            if (state && ai < 2) {
+                v += 0.125 * c.w_rxy;
+                if (ci == cj) v += 2 * c.w_rel; else if (ci + 2 == cj || cj + 2 == ci) v -= 2 * c.w_rel;
+            }
+            if (stage) {
+                v += 0.125 * c.w_zmp;
+                if (ci == cj && ai == 2) v += 2 * c.w_pen;
+            }
+        } else if (cli == V_C && clj == V_Z) {
+            if (stage) v = -0.5 * c.w_zmp;
+        } else if (cli == V_RD && clj == V_RD) {
+            if (state) v = 2 * c.w_rd;
+        } else if (cli == V_CD && clj == V_CD) {
+            if (stage && ai < 2) {
+                if (ci == cj) { const double sw = p_sw(p, ci); v = 2 * c.w_pen * (1.0 + sw * sw); }
+                else if (ci / 2 == cj / 2) v = -2 * c.w_pen;
+            }
+        } else if (cli == V_Z && clj == V_Z) {
+            if (stage) v = 2 * c.w_zmp + e4;
+        } else if (cli == V_CDD && clj == V_CDD) {
+            if (stage && ci == cj) v = 2 * c.gq;
+        }
+        return v;
+    }
+};
+
+using Srbd13 = SrbdModel<2, false>;
+using Srbd37 = SrbdModel<4, true>;
+using Lip30 = LipModel;
+
+}  // namespace sddp

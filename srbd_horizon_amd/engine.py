@@ -1,0 +1,191 @@
+"""Batched DDP engine object: the Python face of one ``sddp_handle`` (include/sddp.h).
+
+Stands where ``pyddp.DdpSolver`` stands in the reference (python/ddp.py:93-94): constructed once, kept across MPC
+ticks, ``solve(params) -> (x, u)``, ``is_converged()``, ``set_initial_state``, ``set_x_warmstart``,
+``set_u_warmstart`` -- widened from one problem to a batch of B independent problems (knot-major C ABI layout).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class DdpEngine:
+    def __init__(self, model: str, N: int, batch: int = 1, opts: dict | None = None, consts: dict | None = None):
+        self.lib = _lib.load()
+        self.model = model
+        self.N, self.B = int(N), int(batch)
+        self.nx, self.nu, self.np_ = _lib.model_dims(model)
+        self.opts = _lib.default_options(**(opts or {}))
+        self.consts = _lib.default_consts(**(consts or {}))
+        h = C.c_void_p()
+        _lib.check(self.lib.sddp_create(C.byref(h), _lib.MODEL_IDS[model], self.N, self.B,
+                                        C.byref(self.opts), C.byref(self.consts)))
+        self.h = h
+        self._keep = []
+
+    # ---- lifetime ------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sddp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        _lib.check(rc, self.h)
+
+    @staticmethod
+    def _c(a, shape):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+        return a
+
+    def set_options(self, **over):
+        for k, v in over.items():
+            if not hasattr(self.opts, k):
+                raise KeyError(f"unknown option {k!r}")
+            setattr(self.opts, k, v)
+        self._chk(self.lib.sddp_set_options(self.h, C.byref(self.opts)))
+
+    # ---- host (numpy) path: [B][N+1][nx] etc. -------------------------------------------------------------------------
+    def set_initial_state(self, x0):
+        a = self._c(x0, (self.B, self.nx))
+        self._chk(self.lib.sddp_set_initial_state(self.h, _lib.ptr(a)))
+
+    def set_x_warmstart(self, x):
+        a = self._c(x, (self.B, self.N + 1, self.nx))
+        self._chk(self.lib.sddp_set_x_warmstart(self.h, _lib.ptr(a)))
+
+    def set_u_warmstart(self, u):
+        a = self._c(u, (self.B, self.N, self.nu))
+        self._chk(self.lib.sddp_set_u_warmstart(self.h, _lib.ptr(a)))
+
+    def solve(self, params):
+        p = self._c(params, (self.B, self.N + 1, self.np_))
+        x = np.empty((self.B, self.N + 1, self.nx))
+        u = np.empty((self.B, self.N, self.nu))
+        st = np.zeros(self.B, dtype=_lib.STATS_DTYPE)
+        self._chk(self.lib.sddp_solve(self.h, _lib.ptr(p), _lib.ptr(x), _lib.ptr(u), _lib.ptr(st)))
+        self.stats = st
+        return x, u
+
+    def is_converged(self):
+        f = np.zeros(self.B, dtype=np.int32)
+        self._chk(self.lib.sddp_is_converged(self.h, _lib.ptr(f)))
+        return f.astype(bool)
+
+    # ---- phase-level entry points (parity tests) ---------------------------------------------------------------------------
+    def backward(self, params, mu=0.0):
+        p = self._c(params, (self.B, self.N + 1, self.np_))
+        gains = np.empty((self.B, self.N, self.nu * (self.nx + 1)))
+        scal = np.empty((self.B, 8))
+        self._chk(self.lib.sddp_backward(self.h, _lib.ptr(p), float(mu), _lib.ptr(gains), _lib.ptr(scal)))
+        kff = gains[:, :, :self.nu]
+        K = gains[:, :, self.nu:].reshape(self.B, self.N, self.nu, self.nx)
+        return kff, K, scal
+
+    def forward(self, params, alpha):
+        p = self._c(params, (self.B, self.N + 1, self.np_))
+        x = np.empty((self.B, self.N + 1, self.nx))
+        u = np.empty((self.B, self.N, self.nu))
+        cost = np.empty(self.B)
+        self._chk(self.lib.sddp_forward(self.h, _lib.ptr(p), float(alpha), _lib.ptr(x), _lib.ptr(u), _lib.ptr(cost)))
+        return x, u, cost
+
+    # ---- HBM-resident path (torch tensors on the GPU; PyTorch is plumbing for device memory and streams) ------------------
+    def _dev(self, t, shape):
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise ValueError("expected a contiguous float64 CUDA tensor")
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return C.c_void_p(t.data_ptr())
+
+    def use_torch_stream(self, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        self._chk(self.lib.sddp_set_stream(self.h, C.c_void_p(s.cuda_stream)))
+
+    def set_initial_state_device(self, x0):
+        self._chk(self.lib.sddp_set_initial_state_device(self.h, self._dev(x0, (self.B, self.nx))))
+
+    def set_x_warmstart_device(self, x):
+        self._chk(self.lib.sddp_set_x_warmstart_device(self.h, self._dev(x, (self.B, self.N + 1, self.nx))))
+
+    def set_u_warmstart_device(self, u):
+        self._chk(self.lib.sddp_set_u_warmstart_device(self.h, self._dev(u, (self.B, self.N, self.nu))))
+
+    def solve_device(self, params):
+        """Asynchronous launch on the handle's stream; results stay in the handle's HBM buffers."""
+        self._chk(self.lib.sddp_solve_device(self.h, self._dev(params, (self.B, self.N + 1, self.np_))))
+
+    def synchronize(self):
+        self._chk(self.lib.sddp_synchronize(self.h))
+
+    def enable_timing(self, on=True):
+        self._chk(self.lib.sddp_enable_timing(self.h, int(on)))
+
+    def last_kernel_ms(self):
+        ms = C.c_double()
+        self._chk(self.lib.sddp_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def device_buffer(self, which: int):
+        p, n = C.c_void_p(), C.c_longlong()
+        self._chk(self.lib.sddp_device_ptr(self.h, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def fetch(self):
+        """Copy the solution and stats of the last device solve to host numpy arrays."""
+        import torch
+        self.synchronize()
+        out = []
+        for which, shape, dt in ((0, (self.B, self.N + 1, self.nx), np.float64), (1, (self.B, self.N, self.nu), np.float64),
+                                 (2, (self.B,), _lib.STATS_DTYPE)):
+            p, n = self.device_buffer(which)
+            host = np.empty(shape, dtype=dt)
+            assert host.nbytes == n
+            _hip_memcpy_dtoh(host, p, n)
+            out.append(host)
+        self.stats = out[2]
+        return out[0], out[1], out[2]
+
+
+def eval_knots(model: str, N: int, k, x, u, p, consts: dict | None = None):
+    """Per-knot model evaluation on the GPU: f, [fx fu], GN Hessian, gradient, cost (parity tests)."""
+    lib = _lib.load()
+    nx, nu, npar = _lib.model_dims(model)
+    nz = nx + nu
+    k = np.ascontiguousarray(k, dtype=np.int32)
+    nk = k.shape[0]
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(nk, nx)
+    u = np.ascontiguousarray(u, dtype=np.float64).reshape(nk, nu)
+    p = np.ascontiguousarray(p, dtype=np.float64).reshape(nk, npar)
+    cst = _lib.default_consts(**(consts or {}))
+    f = np.empty((nk, nx)); F = np.empty((nk, nx, nz)); H = np.empty((nk, nz, nz)); g = np.empty((nk, nz)); L = np.empty(nk)
+    _lib.check(lib.sddp_eval_knots(_lib.MODEL_IDS[model], C.byref(cst), int(N), nk, _lib.ptr(k), _lib.ptr(x), _lib.ptr(u),
+                                   _lib.ptr(p), _lib.ptr(f), _lib.ptr(F), _lib.ptr(H), _lib.ptr(g), _lib.ptr(L)))
+    return f, F, H, g, L
+
+
+_hip = None
+
+
+def _hip_memcpy_dtoh(host: np.ndarray, dptr: int, nbytes: int):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.restype = C.c_int
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = _hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), nbytes, 2)  # hipMemcpyDeviceToHost
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy D2H failed: {rc}")

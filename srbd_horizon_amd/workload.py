@@ -1,0 +1,180 @@
+"""Synthetic, seeded MPC instances: what the bench, the smoke test and the parity tests solve.
+
+Per instance ``seed``:
+  * contact schedule: the walking-pattern scheduler (wpg ``"step"`` action, reference python/wpg.py:80-88) started at
+    phase ``seed mod 20`` and advanced ``N + 1 + seed mod 20`` ticks so the horizon is fully populated; the example
+    loop's per-tick back-shift of rdot_ref / w_ref / oref / orientation gain (python/dsrbd_example.py:102-106) applied;
+  * velocity command: rdot_ref = (0.5 a_x, 0.5 a_y, 0), a ~ U{-1,0,1}^2 (dsrbd_example.py:112, :119-122);
+  * footsteps (srbd13 only, contacts are data): each touchdown moves that foot by one stride = rdot_ref_xy * 1 s;
+  * initial state: nominal + N(0, sigma) (1 cm, 5 cm/s, 0.05 rad/s, small-angle quaternion 0.02), renormalised;
+  * warm start: x = x0 at every node, u = static input (what dsrbd_example.py:61-68 computes).
+
+Everything is computed in closed form, vectorised over the batch: node j of the final horizon was written at tick
+t = T - (N - j), so its value is ``cycle[(phase + t - 1) mod 20]``.  ``schedule_by_ticking`` does the same thing by
+literally ticking ``wpg.steps_phase`` and is used to test the closed form.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import wpg as _wpg
+from .prb import LIPProblem, RobotModel, SRBD13Problem, SRBDProblem
+
+G = 9.81
+
+
+def _schedule_tables(c_init_z=0.0):
+    step_nodes, l_cycle, l_sw, r_cycle, r_sw = _wpg.step_tables(c_init_z)
+    return step_nodes, np.stack([l_cycle, r_cycle]), np.stack([l_sw, r_sw])
+
+
+def _closed_form(N, seeds, init_z, init_sw, init_otg):
+    """-> z_ref [B,2,N+1], sw [B,2,N+1], otg [B,N+1], n_td [B,2,N+1] (touchdowns of each foot up to node j)."""
+    seeds = np.asarray(seeds, dtype=np.int64)
+    B = seeds.shape[0]
+    step_nodes, cyc, swt = _schedule_tables(0.0)
+    period = 2 * step_nodes
+    phase = seeds % period
+    T = N + 1 + phase                                    # ticks executed
+    j = np.arange(N + 1)[None, :]
+    t = T[:, None] - (N - j)                             # tick (1-based) that wrote node j; all >= 1 here
+    idx = (phase[:, None] + t - 1) % period
+    z = np.stack([cyc[0][idx], cyc[1][idx]], axis=1)
+    sw = np.stack([swt[0][idx], swt[1][idx]], axis=1)
+    otg = np.full((B, N + 1), 1e2)                       # wpg writes 1e2 at node N each tick (wpg.py:82), then shifted back
+    # touchdowns: switch goes 0 -> 1 between consecutive ticks; count along the global tick timeline
+    n_td = np.zeros((B, 2, N + 1))
+    tick_all = np.arange(1, int(T.max()) + 1)
+    for leg in range(2):
+        sw_all = swt[leg][(phase[:, None] + tick_all[None, :] - 1) % period]          # [B, Tmax]
+        prev = np.concatenate([np.ones((B, 1)), sw_all[:, :-1]], axis=1)
+        td = ((prev == 0.0) & (sw_all == 1.0)).astype(float)
+        cum = np.cumsum(td, axis=1)
+        n_td[:, leg, :] = np.take_along_axis(cum, t - 1, axis=1)
+    return z, sw, otg, n_td
+
+
+def make_srbd13_batch(N: int, seeds, robot: RobotModel | None = None):
+    """-> dict(x0 [B,13], params [B,N+1,19], xs [B,N+1,13], us [B,N,6], consts) for the metric model."""
+    robot = robot or RobotModel()
+    seeds = np.asarray(seeds, dtype=np.int64)
+    B = seeds.shape[0]
+    pb = SRBD13Problem()
+    pb.createSRBD13Problem(N, N * 0.05, robot)
+    z, sw, otg, n_td = _closed_form(N, seeds, 0.0, 1.0, 1e1)
+    a = np.stack([np.random.default_rng(int(s)).integers(-1, 2, size=2) for s in seeds]).astype(float)
+    v = 0.5 * a                                                              # alphaX = alphaY = 0.5 when walking
+    P = np.zeros((B, N + 1, 19))
+    P[:, :, 0:2] = v[:, None, :]                                             # rdot_ref
+    P[:, :, 6] = otg
+    P[:, :, 7:11] = np.array([-0.0, -0.0, -0.0, 1.0])                        # oref
+    for leg in range(2):
+        c0 = pb.initial_foot_position[leg]
+        P[:, :, 11 + 3 * leg + 0] = c0[0] + v[:, None, 0] * 1.0 * n_td[:, leg, :]
+        P[:, :, 11 + 3 * leg + 1] = c0[1] + v[:, None, 1] * 1.0 * n_td[:, leg, :]
+        P[:, :, 11 + 3 * leg + 2] = z[:, leg, :]
+        P[:, :, 17 + leg] = sw[:, leg, :]
+    x0 = np.tile(pb.getInitialState(), (B, 1))
+    for b, s in enumerate(seeds):
+        rng = np.random.default_rng(int(s) + 1_000_003)
+        x0[b, 0:3] += 0.01 * rng.standard_normal(3)
+        dq = 0.02 * rng.standard_normal(3)
+        q = np.array([dq[0], dq[1], dq[2], 1.0])
+        x0[b, 3:7] = q / np.linalg.norm(q)
+        x0[b, 7:10] += 0.05 * rng.standard_normal(3)
+        x0[b, 10:13] += 0.05 * rng.standard_normal(3)
+    xs = np.repeat(x0[:, None, :], N + 1, axis=1)
+    us = np.tile(pb.getStaticInput(), (B, N, 1))
+    return dict(x0=x0, params=P, xs=xs, us=us, consts=pb.prb.model_consts, problem=pb)
+
+
+def schedule_by_ticking(N: int, seed: int, robot: RobotModel | None = None):
+    """The same srbd13 parameter tensor, produced by literally running the receding-horizon bookkeeping."""
+    robot = robot or RobotModel()
+    pb = SRBD13Problem()
+    pb.createSRBD13Problem(N, N * 0.05, robot)
+    gen = _wpg.steps_phase(pb.f, pb.c, pb.cdot, 0.0, pb.c_ref, pb.w_ref, pb.orientation_tracking_gain, pb.cdot_switch,
+                           N, number_of_legs=2, contact_model=1)
+    phase = seed % 20
+    gen.step_counter = phase
+    a = np.random.default_rng(int(seed)).integers(-1, 2, size=2).astype(float)
+    v = 0.5 * a
+    pb.rdot_ref.assign([v[0], v[1], 0.0])
+    prev_sw = [1.0, 1.0]
+    for _ in range(N + 1 + phase):
+        for par in (pb.rdot_ref, pb.w_ref, pb.oref, pb.orientation_tracking_gain):     # dsrbd_example.py:102-106
+            par.values[:, :N] = par.values[:, 1:N + 1]
+        for i in range(2):                                                              # footstep xy rides with the plan
+            pb.c[i].values[0:2, :N] = pb.c[i].values[0:2, 1:N + 1]
+        pb.rdot_ref.assign([v[0], v[1], 0.0], nodes=N)
+        gen.set("step")
+        for i in range(2):
+            sw_new = pb.cdot_switch[i].values[0, N]
+            xy = pb.c[i].values[0:2, N - 1].copy()
+            if prev_sw[i] == 0.0 and sw_new == 1.0:
+                xy = xy + v * 1.0
+            pb.c[i].values[0:2, N] = xy
+            prev_sw[i] = sw_new
+    return pb.prb.parameter_matrix()
+
+
+def make_srbd37_batch(N: int, seeds, robot: RobotModel | None = None):
+    """Reference-faithful SRBD (nc = 4 line feet, launch:16-17): the line-foot contact schedule of config 5."""
+    robot = robot or RobotModel()
+    seeds = np.asarray(seeds, dtype=np.int64)
+    B = seeds.shape[0]
+    pb = SRBDProblem()
+    pb.createSRBDProblem(N, N * 0.05, robot)
+    z, sw, otg, _ = _closed_form(N, seeds, 0.0, 1.0, 1e1)
+    a = np.stack([np.random.default_rng(int(s)).integers(-1, 2, size=2) for s in seeds]).astype(float)
+    P = np.zeros((B, N + 1, 19))
+    P[:, :, 0:2] = 0.5 * a[:, None, :]
+    P[:, :, 6] = otg
+    for i in range(4):
+        leg = 0 if i < 2 else 1
+        P[:, :, 7 + 2 * i] = z[:, leg, :]
+        P[:, :, 8 + 2 * i] = sw[:, leg, :]
+    P[:, :, 15:19] = np.array([-0.0, -0.0, -0.0, 1.0])
+    x0 = np.tile(pb.getInitialState(), (B, 1))
+    for b, s in enumerate(seeds):
+        rng = np.random.default_rng(int(s) + 1_000_003)
+        x0[b, 0:3] += 0.01 * rng.standard_normal(3)
+        dq = 0.02 * rng.standard_normal(3)
+        q = np.array([dq[0], dq[1], dq[2], 1.0])
+        x0[b, 3:7] = q / np.linalg.norm(q)
+        x0[b, 19:22] += 0.05 * rng.standard_normal(3)
+        x0[b, 22:25] += 0.05 * rng.standard_normal(3)
+    xs = np.repeat(x0[:, None, :], N + 1, axis=1)
+    us = np.tile(pb.getStaticInput(), (B, N, 1))
+    return dict(x0=x0, params=P, xs=xs, us=us, consts=pb.prb.model_consts, problem=pb)
+
+
+def make_lip30_batch(N: int, seeds, robot: RobotModel | None = None):
+    robot = robot or RobotModel()
+    seeds = np.asarray(seeds, dtype=np.int64)
+    B = seeds.shape[0]
+    pb = LIPProblem()
+    pb.createLIPProblem(N, N * 0.05, robot)
+    z, sw, _, _ = _closed_form(N, seeds, 0.0, 1.0, 1e1)
+    a = np.stack([np.random.default_rng(int(s)).integers(-1, 2, size=2) for s in seeds]).astype(float)
+    P = np.zeros((B, N + 1, 11))
+    P[:, :, 0:2] = 0.5 * a[:, None, :]
+    for i in range(4):
+        leg = 0 if i < 2 else 1
+        P[:, :, 3 + 2 * i] = z[:, leg, :]
+        P[:, :, 4 + 2 * i] = sw[:, leg, :]
+    x0 = np.tile(pb.getInitialState(), (B, 1))
+    for b, s in enumerate(seeds):
+        rng = np.random.default_rng(int(s) + 1_000_003)
+        x0[b, 0:3] += 0.01 * rng.standard_normal(3)
+        x0[b, 15:18] += 0.05 * rng.standard_normal(3)
+    xs = np.repeat(x0[:, None, :], N + 1, axis=1)
+    us = np.tile(pb.getStaticInput(), (B, N, 1))
+    return dict(x0=x0, params=P, xs=xs, us=us, consts=pb.prb.model_consts, problem=pb)
+
+
+MAKERS = {"srbd13": make_srbd13_batch, "srbd37": make_srbd37_batch, "lip30": make_lip30_batch}
+
+
+def make_batch(model: str, N: int, seeds, robot: RobotModel | None = None):
+    return MAKERS[model](N, seeds, robot)

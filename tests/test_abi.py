@@ -1,0 +1,51 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/sddp.h declares (no compute calls without a GPU); the product path fails loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from srbd_horizon_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_all_bound_and_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "sddp.h")).read()
+    declared = set(re.findall(r"\b(sddp_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_struct_layouts_and_dims(lib):
+    assert lib.sddp_abi_version() == 1
+    assert _lib.model_dims("srbd13") == (13, 6, 19)
+    assert _lib.model_dims("srbd37") == (37, 24, 19)
+    assert _lib.model_dims("lip30") == (30, 15, 11)
+    o = _lib.default_options()
+    # Python-side defaults of the reference adapter (ddp.py:17-29)
+    assert (o.max_iters, o.alpha_0, o.alpha_converge_threshold, o.line_search_decrease_factor, o.beta) == (100, 1.0, 1e-1, 0.5, 1e-4)
+    c = _lib.default_consts()
+    assert c.force_scaling == 1000.0 and c.dt == 0.05 and c.inertia_mode == 0 and abs(c.com[2] - 0.88) < 1e-15
+    assert C.sizeof(_lib.SddpStats) == 56
+
+
+def test_no_cpu_fallback_without_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    rc = lib.sddp_create(C.byref(h), 0, 30, 1, None, None)
+    assert rc != 0 and not h.value
+    assert b"no HIP device" in lib.sddp_last_error(None)
+    from srbd_horizon_amd.engine import DdpEngine
+    with pytest.raises(RuntimeError):
+        DdpEngine("srbd13", 30, 1)

@@ -1,0 +1,212 @@
+"""GPU parity tests proper: the HIP engine (through the C ABI) vs the float64 CPU oracle on the same seeded inputs.
+
+Tolerances (floating point, fp64 on both sides; BASELINE.json target is <= 1e-4 l-inf on trajectories):
+  per-knot model evaluation   rtol 1e-11 (same formulas, different operation order / FMA contraction)
+  one backward sweep          gains rtol 1e-8  (30 dependent 13x13 Riccati steps, cond ~1e6)
+  one forward pass            1e-9
+  converged solves            l-inf(x,u) <= 1e-6, relative cost <= 1e-9, same iteration count
+"""
+import numpy as np
+import pytest
+
+from oracle import ddp as oddp
+from oracle import models as omodels
+from srbd_horizon_amd import workload
+from srbd_horizon_amd.engine import DdpEngine, eval_knots
+
+pytestmark = pytest.mark.gpu
+
+MODELS = ["srbd13", "srbd37", "lip30"]
+
+
+def _oracle_model(name, consts=None):
+    cst = omodels.RobotConsts()
+    for k, v in (consts or {}).items():
+        if hasattr(cst, k):
+            setattr(cst, k, v)
+    return omodels.make_model(name, cst)
+
+
+def _opts(**over):
+    o = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsrbd_example.py:55-58
+    o.update(over)
+    return o
+
+
+def _oracle_opts(**over):
+    return oddp.DdpOptions(**_opts(**over))
+
+
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("imode,lever", [(0, 1.0), (1, -1.0)])
+def test_eval_knots_matches_oracle(name, imode, lever):
+    if name == "lip30" and imode == 1:
+        pytest.skip("LIP has no inertia")
+    N = 20
+    m = _oracle_model(name, dict(inertia_mode=imode, lever_sign=lever))
+    rng = np.random.default_rng(5)
+    ks = np.array([0, 1, 7, N - 1, N, 3, N, 0], dtype=np.int32)
+    nk = len(ks)
+    X = np.tile(m.initial_state(), (nk, 1)) + 0.05 * rng.standard_normal((nk, m.nx))
+    U = np.tile(m.static_input(), (nk, 1)) + 0.05 * rng.standard_normal((nk, m.nu))
+    P = np.tile(m.default_params(N)[3], (nk, 1)) + 0.05 * rng.standard_normal((nk, m.np_))
+    f, F, H, g, L = eval_knots(name, N, ks, X, U, P, consts=dict(inertia_mode=imode, lever_sign=lever))
+    for t, k in enumerate(ks):
+        if k < N:
+            np.testing.assert_allclose(f[t], m.f(X[t], U[t], P[t]), rtol=1e-12, atol=1e-13)
+            fx, fu = m.f_jac(X[t], U[t], P[t])
+            np.testing.assert_allclose(F[t], np.hstack([fx, fu]), rtol=1e-11, atol=1e-12)
+            Lo, lx, lu, lxx, lux, luu = m.cost_derivs(X[t], U[t], P[t], int(k))
+            Ho = np.block([[lxx, lux.T], [lux, luu]])
+            go = np.concatenate([lx, lu])
+        else:
+            Lo, lx, _, lxx, _, _ = m.cost_derivs(X[t], None, P[t], int(k))
+            Ho = np.zeros((m.nx + m.nu,) * 2); Ho[:m.nx, :m.nx] = lxx
+            go = np.concatenate([lx, np.zeros(m.nu)])
+        assert abs(L[t] - Lo) <= 1e-12 * max(1.0, abs(Lo))
+        np.testing.assert_allclose(g[t], go, rtol=1e-11, atol=1e-11 * max(1.0, np.max(np.abs(go))))
+        np.testing.assert_allclose(H[t], Ho, rtol=1e-11, atol=1e-11 * max(1.0, np.max(np.abs(Ho))))
+
+
+@pytest.mark.parametrize("name,N", [("srbd13", 30), ("srbd37", 20), ("lip30", 20)])
+def test_backward_and_forward_pass_match_oracle(name, N):
+    seeds = [0, 5, 13]
+    batch = workload.make_batch(name, N, seeds)
+    m = _oracle_model(name)
+    rng = np.random.default_rng(1)
+    xs = batch["xs"] + 0.01 * rng.standard_normal(batch["xs"].shape)       # open gaps: multiple shooting
+    us = batch["us"] + 0.01 * rng.standard_normal(batch["us"].shape)
+    xs[:, 0] = batch["x0"]
+    eng = DdpEngine(name, N, len(seeds), opts=_opts())
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(xs); eng.set_u_warmstart(us)
+    kff, K, scal = eng.backward(batch["params"], mu=0.0)
+    xg, ug, Jg = eng.forward(batch["params"], 0.5)
+    for b in range(len(seeds)):
+        P = batch["params"][b]
+        d = oddp.defects(m, xs[b], us[b], P)
+        ok, Ko, ko, dV1, dV2, G1, G2, Vx0, Vxx0, qu = oddp.backward_pass(m, xs[b], us[b], P, d, 0.0)
+        assert ok and scal[b, 4] == 1.0
+        sK = max(1.0, np.max(np.abs(Ko)))
+        np.testing.assert_allclose(K[b], Ko, rtol=1e-7, atol=1e-8 * sK)
+        np.testing.assert_allclose(kff[b], ko, rtol=1e-7, atol=1e-8 * max(1.0, np.max(np.abs(ko))))
+        for got, ref in ((scal[b, 0], dV1), (scal[b, 1], dV2), (scal[b, 2], G1), (scal[b, 3], G2)):
+            assert abs(got - ref) <= 1e-8 * max(1.0, abs(ref), abs(dV1))
+        assert abs(scal[b, 7] - oddp.total_cost(m, xs[b], us[b], P)) <= 1e-11 * abs(scal[b, 7])
+        xo, uo, Jo = oddp.forward_pass(m, batch["x0"][b], xs[b], us[b], P, d, Ko, ko, 0.5)
+        np.testing.assert_allclose(xg[b], xo, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(ug[b], uo, rtol=0, atol=1e-8)
+        assert abs(Jg[b] - Jo) <= 1e-9 * abs(Jo)
+
+
+@pytest.mark.parametrize("name,N,initial_rollout", [("srbd13", 30, 0), ("srbd13", 30, 1), ("srbd37", 20, 0),
+                                                    ("lip30", 20, 0)])
+def test_converged_solve_matches_oracle(name, N, initial_rollout):
+    seeds = [1, 2, 7, 16]
+    batch = workload.make_batch(name, N, seeds)
+    m = _oracle_model(name)
+    over = dict(initial_rollout=initial_rollout, cost_reduction_ths=1e-9)
+    eng = DdpEngine(name, N, len(seeds), opts=_opts(**over))
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    st = eng.stats
+    conv = eng.is_converged()
+    for b in range(len(seeds)):
+        o = _oracle_opts(**over)
+        o.initial_rollout = bool(initial_rollout)
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], o)
+        assert r.converged and conv[b] and st["status"][b] == 0
+        assert st["iters"][b] == r.iters, (st["iters"][b], r.iters)
+        assert np.max(np.abs(x[b] - r.xs)) <= 1e-6
+        assert np.max(np.abs(u[b] - r.us)) <= 1e-6
+        assert abs(st["cost"][b] - r.cost) <= 1e-9 * abs(r.cost)
+        assert st["gap"][b] <= 1e-9
+
+
+def test_iteration_by_iteration_trace_matches_oracle():
+    """max_iters = 1, 2, 3: the engine and the oracle agree after every iteration, not only at convergence."""
+    N, seeds = 30, [4]
+    batch = workload.make_batch("srbd13", N, seeds)
+    m = _oracle_model("srbd13")
+    for it in (1, 2, 3):
+        eng = DdpEngine("srbd13", N, 1, opts=_opts(max_iters=it, cost_reduction_ths=1e-12))
+        eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+        x, u = eng.solve(batch["params"])
+        r = oddp.solve(m, batch["x0"][0], batch["params"][0], batch["xs"][0], batch["us"][0],
+                       _oracle_opts(max_iters=it, cost_reduction_ths=1e-12))
+        assert eng.stats["iters"][0] == r.iters == it
+        assert eng.stats["alpha"][0] == r.alpha
+        assert np.max(np.abs(x[0] - r.xs)) <= 1e-8 and np.max(np.abs(u[0] - r.us)) <= 1e-8
+        assert abs(eng.stats["cost"][0] - r.cost) <= 1e-10 * abs(r.cost)
+        eng.close()
+
+
+def test_regularisation_bump_on_indefinite_quu():
+    """mu0 < 0 large makes Quu indefinite: the engine must bump mu (ddp.py:34-35) exactly like the oracle."""
+    N, seeds = 30, [3]
+    batch = workload.make_batch("srbd13", N, seeds)
+    m = _oracle_model("srbd13")
+    over = dict(mu0=-1e9, max_iters=3)
+    eng = DdpEngine("srbd13", N, 1, opts=_opts(**over))
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    r = oddp.solve(m, batch["x0"][0], batch["params"][0], batch["xs"][0], batch["us"][0], _oracle_opts(**over))
+    assert eng.stats["mu"][0] == pytest.approx(r.mu, rel=1e-12)
+    assert eng.stats["iters"][0] == r.iters
+    assert np.max(np.abs(x[0] - r.xs)) <= 1e-7
+
+
+def test_backtracking_line_search_picks_the_same_alpha():
+    """A far-off warm start forces alpha < 1: the one-pass parallel ladder must select what sequential backtracking selects."""
+    N = 30
+    batch = workload.make_batch("srbd13", N, [9])
+    m = _oracle_model("srbd13")
+    rng = np.random.default_rng(2)
+    us = batch["us"] + 0.3 * rng.standard_normal(batch["us"].shape)
+    xs = batch["xs"].copy()
+    xs[:, 1:, 3:7] += 0.4 * rng.standard_normal((1, N, 4))
+    over = dict(max_iters=4, cost_reduction_ths=1e-12, beta=0.5)
+    eng = DdpEngine("srbd13", N, 1, opts=_opts(**over))
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(xs); eng.set_u_warmstart(us)
+    x, u = eng.solve(batch["params"])
+    r = oddp.solve(m, batch["x0"][0], batch["params"][0], xs[0], us[0], _oracle_opts(**over))
+    alphas = [t["alpha"] for t in r.trace]
+    assert eng.stats["iters"][0] == r.iters
+    assert eng.stats["alpha"][0] == r.alpha
+    assert np.max(np.abs(x[0] - r.xs)) <= 1e-7
+    assert min(alphas) < 1.0, "test input does not exercise backtracking"
+
+
+def test_full_size_batch_properties():
+    """BASELINE config 3 size (B = 1024, N = 30): size-independent properties + spot parity on a few instances."""
+    N, B = 30, 1024
+    batch = workload.make_batch("srbd13", N, np.arange(B))
+    eng = DdpEngine("srbd13", N, B, opts=_opts())
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    st = eng.stats
+    assert np.all(st["converged"] == 1) and np.all(st["status"] == 0)
+    assert np.all(np.isfinite(x)) and np.all(np.isfinite(u))
+    np.testing.assert_array_equal(x[:, 0], batch["x0"])                     # x_0 is pinned
+    m = _oracle_model("srbd13")
+    # dynamic feasibility of every instance (gaps closed): x_{k+1} = f(x_k,u_k) -- checked with the oracle's f
+    for b in range(0, B, 97):
+        d = oddp.defects(m, x[b], u[b], batch["params"][b])
+        assert np.max(np.abs(d)) <= 1e-9
+        assert abs(oddp.total_cost(m, x[b], u[b], batch["params"][b]) - st["cost"][b]) <= 1e-9 * st["cost"][b]
+    # idempotence: re-solving from the solution takes zero iterations and returns it unchanged
+    eng.set_x_warmstart(x); eng.set_u_warmstart(u)
+    x2, u2 = eng.solve(batch["params"])
+    assert np.all(eng.stats["iters"] == 0)
+    np.testing.assert_array_equal(x2, x); np.testing.assert_array_equal(u2, u)
+    # batch independence: instance b solved alone gives bit-identical output
+    for b in (0, 511, 1023):
+        e1 = DdpEngine("srbd13", N, 1, opts=_opts())
+        e1.set_initial_state(batch["x0"][b:b + 1]); e1.set_x_warmstart(batch["xs"][b:b + 1]); e1.set_u_warmstart(batch["us"][b:b + 1])
+        x1, u1 = e1.solve(batch["params"][b:b + 1])
+        np.testing.assert_array_equal(x1[0], x[b]); np.testing.assert_array_equal(u1[0], u[b])
+        e1.close()
+    # spot parity against the oracle
+    for b in (0, 300, 777):
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], _oracle_opts())
+        assert np.max(np.abs(x[b] - r.xs)) <= 1e-4 and np.max(np.abs(u[b] - r.us)) <= 1e-4
+        assert abs(st["cost"][b] - r.cost) <= 1e-6 * abs(r.cost)
