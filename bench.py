@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- SRBD-DDP solves/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: B = 1024 independent SRBD MPC instances per
+GPU (BASELINE configs[2]; 8 GPUs x 1024 = configs[3]), N = 30 knots, nx = 13, nu = 6, each solved from a cold
+warm start (x = x0 at every node, u = static input) to convergence with the reference example's solver options
+(dsrbd_example.py:55-58).  Inputs are resident in HBM before the timed region; a step = reset warm start (D2D) + the
+fused persistent solve kernel (+ the RCCL all-gather of the solution records when N > 1).  Weak scaling.
+
+Rank 0 prints ONE JSON line; `roofline` and `cpu_baseline` are defined in DESIGN.md ("Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+W = 8                     # bytes per fp64 word
+
+
+def algorithmic_bytes(N, nx, nu, npar, iters, rollouts, B):
+    """per DDP iteration [read knots + write gains + accepted trajectory write] plus, per rollout,
+    [gains + trajectory reads]; per solve the I/O of params, x0, warm start in and solution out."""
+    it = W * (N * (nx + nu + npar) + nx + npar + N * (nu * nx + nu) + N * (nx + nu) + nx)
+    ro = W * (N * (nu * nx + nu) + N * (nx + nu) + nx)
+    io = W * ((N + 1) * npar + nx + 2 * ((N + 1) * nx + N * nu))
+    return float(np.sum(iters) * it + np.sum(rollouts) * ro + B * io)
+
+
+def cpu_baseline(N, budget_s=15.0):
+    """The oracle (numpy float64 restatement, 1 core) timed on a bounded sample of the same workload."""
+    from oracle import ddp as oddp, models as omodels
+    from srbd_horizon_amd import workload
+    m = omodels.make_model("srbd13")
+    opts = oddp.DdpOptions(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
+    seeds = list(range(64))
+    batch = workload.make_batch("srbd13", N, seeds)
+    t0 = time.perf_counter()
+    n = iters = 0
+    for b in range(len(seeds)):
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], opts)
+        n += 1
+        iters += r.iters
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} instances (seeds 0..{n - 1}) of the bench workload, {iters} DDP iterations, "
+                      f"{dt:.1f} s, numpy float64 oracle (oracle/ddp.py), host has {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="MPC instances per GPU")
+    ap.add_argument("--horizon", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from srbd_horizon_amd import workload
+    from srbd_horizon_amd.engine import DdpEngine
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the DDP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    N, B = args.horizon, args.batch
+    nx, nu, npar = 13, 6, 19
+    seeds = rank * B + np.arange(B)                        # instances are sharded contiguously across ranks
+    batch = workload.make_batch("srbd13", N, seeds)
+    opts = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsrbd_example.py:55-58
+    eng = DdpEngine("srbd13", N, B, opts=opts)
+    eng.use_torch_stream()                                 # kernels run on torch's current stream
+    eng.enable_timing(True)
+    d_x0 = torch.from_numpy(batch["x0"]).to(dev)
+    d_xs = torch.from_numpy(batch["xs"]).to(dev)
+    d_us = torch.from_numpy(batch["us"]).to(dev)
+    d_P = torch.from_numpy(batch["params"]).to(dev)
+    rec_words = (N + 1) * nx + N * nu + 2                  # trajectory + (cost, iters)
+    if world > 1:
+        send = torch.empty((B, rec_words), dtype=torch.float64, device=dev)
+        gathered = torch.empty((world * B, rec_words), dtype=torch.float64, device=dev)
+    views = eng.fetch_device_views()
+
+    def step():
+        eng.set_initial_state_device(d_x0)
+        eng.set_x_warmstart_device(d_xs)
+        eng.set_u_warmstart_device(d_us)
+        eng.solve_device(d_P)
+        eng.synchronize()                                  # also latches the kernel's HIP-event duration
+        if world > 1:
+            x, u, sf, si = views
+            send[:, :(N + 1) * nx] = x.reshape(B, -1)
+            send[:, (N + 1) * nx:(N + 1) * nx + N * nu] = u.reshape(B, -1)
+            send[:, -2] = sf[:, 0]                          # cost
+            send[:, -1] = si[:, 10].to(torch.float64)       # iters
+            dist.all_gather_into_tensor(gathered, send)   # RCCL over xGMI
+        return eng.last_kernel_ms()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kern_ms = []
+    for _ in range(args.steps):
+        kern_ms.append(step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    x, u, st = eng.fetch()
+    iters, rollouts = st["iters"].astype(np.int64), st["rollouts"].astype(np.int64)
+    kms = float(np.mean(kern_ms))
+    abytes = algorithmic_bytes(N, nx, nu, npar, iters, rollouts, B)
+    achieved = abytes / (kms * 1e-3) / 1e9
+    out = {
+        "metric": "SRBD-DDP solves/sec (N=30, nx=13, nu=6)", "value": world * B * args.steps / elapsed, "unit": "solves/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"SRBD N={N} nx=13 nu=6, batch={B} independent MPC instances per GPU "
+                               "(BASELINE configs[2]; x8 GPUs = configs[3]), cold start, whole line-search ladder "
+                               "(alpha=1..1e-12, 40 candidates) rolled out per iteration",
+                   "batch_per_gpu": B, "horizon_N": N, "solver_opts": opts, "algorithm": "MS-DDP, Gauss-Newton Hessians",
+                   "collective": "all_gather(solution records) per step" if world > 1 else "none"},
+        "mean_iters": float(np.mean(iters)), "max_iters_hit_frac": float(np.mean(st["status"] == 1)),
+        "converged_frac": float(np.mean(st["converged"] == 1)), "mean_rollouts": float(np.mean(rollouts)),
+        "iterations_per_s": world * float(np.sum(iters)) * args.steps / elapsed,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "solve_kernel<SrbdModel<2,false>>", "kernel_ms": kms,
+                     "algorithmic_bytes_per_launch": abytes},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ms / MPC tick, configs[1]: one instance, host-pointer call (PCIe included), cold start
+        e1 = DdpEngine("srbd13", N, 1, opts=opts)
+        b1 = workload.make_batch("srbd13", N, [0])
+        ticks = []
+        for _ in range(30):
+            e1.set_initial_state(b1["x0"]); e1.set_x_warmstart(b1["xs"]); e1.set_u_warmstart(b1["us"])
+            t1 = time.perf_counter()
+            e1.solve(b1["params"])
+            ticks.append(1e3 * (time.perf_counter() - t1))
+        out["ms_per_mpc_tick_b1"] = {"median": float(np.median(ticks[5:])), "p99": float(np.percentile(ticks[5:], 99)),
+                                     "iters": int(e1.stats["iters"][0]), "note": "B=1, seed 0, cold start, host-pointer sddp_solve (PCIe-inclusive)"}
+        out["cpu_baseline"] = cpu_baseline(N)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -177,7 +177,7 @@ def solve(model, x0, P, xs_ws, us_ws, opt: DdpOptions | None = None) -> DdpResul
             a *= opt.line_search_decrease_factor
         if not accepted:
             converged, status = True, 0          # alpha fell below alpha_converge_threshold (App. C)
-            alpha = a
+            alpha = 0.0
             break
         alpha = a
         dJ = J - Jn

@@ -107,6 +107,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the DDP engine)")
+    try:
+        # PyTorch bundles its own HIP runtime with the same soname (libamdhip64.so.7).  Load it first so the process has
+        # ONE HIP runtime shared by torch tensors / streams and this library (loading the system one first and torch's
+        # second leaves this library without a visible device).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported

@@ -408,9 +408,8 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
                     break;
                 }
                 a_base = __shfl(a, kWave - 1, kWave) * o.line_search_decrease_factor;
-                alpha = __shfl(a, kWave - 1, kWave);
             }
-            if (!accepted) { converged = 1; status = 0; break; }  // alpha fell below alpha_converge_threshold
+            if (!accepted) { alpha = 0.0; converged = 1; status = 0; break; }  // alpha fell below alpha_converge_threshold
             alpha = a_win;
             const double dJ = J - J_win;
             J = J_win;

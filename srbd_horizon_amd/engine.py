@@ -144,6 +144,25 @@ class DdpEngine:
         self._chk(self.lib.sddp_device_ptr(self.h, which, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def fetch_device_views(self):
+        """Zero-copy torch views of the handle's HBM buffers: x [B,N+1,nx], u [B,N,nu], stats as f64 [B,7] and i32 [B,14]
+        (sddp_stats: cost, alpha, gap, mu, expected | iters, converged, status, rollouts)."""
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        class _Dev:
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+        px, _ = self.device_buffer(0)
+        pu, _ = self.device_buffer(1)
+        ps, _ = self.device_buffer(2)
+        x = torch.as_tensor(_Dev(px, (self.B, self.N + 1, self.nx), "<f8"), device=dev)
+        u = torch.as_tensor(_Dev(pu, (self.B, self.N, self.nu), "<f8"), device=dev)
+        sf = torch.as_tensor(_Dev(ps, (self.B, 7), "<f8"), device=dev)
+        si = torch.as_tensor(_Dev(ps, (self.B, 14), "<i4"), device=dev)
+        return x, u, sf, si
+
     def fetch(self):
         """Copy the solution and stats of the last device solve to host numpy arrays."""
         import torch
