@@ -1,0 +1,22 @@
+"""Diagnostic: per-phase shader-cycle shares of the fused solve kernel (build with -DSDDP_STAMPS, SDDP_LIB=...)."""
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, '.')
+from srbd_horizon_amd import workload, _lib
+from srbd_horizon_amd.engine import DdpEngine
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+N = 30
+batch = workload.make_batch("srbd13", N, np.arange(B))
+eng = DdpEngine("srbd13", N, B, opts=dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3))
+eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+eng.enable_timing(True)
+x, u = eng.solve(batch["params"])
+sc = np.zeros((B, 16))
+fn = eng.lib.sddp_debug_read_scal; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p]
+assert fn(eng.h, sc.ctypes.data_as(C.c_void_p)) == 0
+it = eng.stats["iters"]; ro = eng.stats["rollouts"]
+names = ["derivs", "bw.stage", "bw.expand+vp", "bw.W=VxxF", "bw.Q=H+FtW", "bw.solve", "bw.Vupd+gains", "-", "rollout", "other"]
+tot = sc[:, :10].sum(axis=1)
+print("kernel ms", eng.last_kernel_ms(), "mean iters", it.mean(), "mean rollouts", ro.mean())
+print("cycles/iter (mean over instances): %.0f" % (tot / np.maximum(it, 1)).mean())
+for i, n in enumerate(names):
+    print("  %-14s %6.1f%%  %10.0f cyc/iter" % (n, 100 * sc[:, i].sum() / tot.sum(), (sc[:, i] / np.maximum(it, 1)).mean()))

@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libsddp_hip.so")
+LIB_PATH = os.environ.get("SDDP_LIB", os.path.join(_HERE, "libsddp_hip.so"))   # SDDP_LIB: diagnostic builds only
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 

@@ -215,7 +215,7 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (e == hipSuccess) e = alloc((void**)&h->dft, size_t(batch) * N * d.nx * D);
     if (e == hipSuccess) e = alloc((void**)&h->gains, h->n_g() * D);
     if (e == hipSuccess) e = alloc((void**)&h->rec, size_t(batch) * (N + 1) * d.nrec * D);
-    if (e == hipSuccess) e = alloc((void**)&h->scal, size_t(batch) * 8 * D);
+    if (e == hipSuccess) e = alloc((void**)&h->scal, size_t(batch) * kScal * D);
     if (e == hipSuccess) e = alloc((void**)&h->stats, size_t(batch) * sizeof(sddp_stats));
     if (e == hipSuccess) e = hipMemset(h->stats, 0, size_t(batch) * sizeof(sddp_stats));
     if (e == hipSuccess) e = hipMemset(h->dft, 0, size_t(batch) * N * d.nx * D);
@@ -428,8 +428,13 @@ int sddp_backward(sddp_handle* h, const double* params, double mu, double* gains
     DISPATCH(h, launch_backward, h, a);
     if (rc != SDDP_OK) return rc;
     if (gains_out) HIP_TRY(h, hipMemcpyAsync(gains_out, h->gains, h->n_g() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (scal_out) HIP_TRY(h, hipMemcpyAsync(scal_out, h->scal, size_t(h->B) * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (scal_out) {
+        std::vector<double> sc(size_t(h->B) * kScal);
+        HIP_TRY(h, hipMemcpy(sc.data(), h->scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int b = 0; b < h->B; ++b)
+            for (int i = 0; i < 8; ++i) scal_out[size_t(b) * 8 + i] = sc[size_t(b) * kScal + i];
+    }
     return SDDP_OK;
 }
 
@@ -446,10 +451,18 @@ int sddp_forward(sddp_handle* h, const double* params, double alpha, double* x_o
     if (u_out) HIP_TRY(h, hipMemcpyAsync(u_out, h->un, h->n_u() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (cost_out) {
-        std::vector<double> sc(size_t(h->B) * 8);
+        std::vector<double> sc(size_t(h->B) * kScal);
         HIP_TRY(h, hipMemcpy(sc.data(), h->scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost));
-        for (int b = 0; b < h->B; ++b) cost_out[b] = sc[size_t(b) * 8];
+        for (int b = 0; b < h->B; ++b) cost_out[b] = sc[size_t(b) * kScal];
     }
+    return SDDP_OK;
+}
+
+// diagnostic (not part of include/sddp.h): raw [B][16] scratch record; holds per-phase cycle sums in a -DSDDP_STAMPS build
+int sddp_debug_read_scal(sddp_handle* h, double* out) {
+    if (!h || !out) return SDDP_ERR_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out, h->scal, size_t(h->B) * kScal * sizeof(double), hipMemcpyDeviceToHost));
     return SDDP_OK;
 }
 

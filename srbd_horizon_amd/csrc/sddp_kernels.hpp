@@ -24,6 +24,20 @@
 namespace sddp {
 
 constexpr int kWave = 64;
+constexpr int kScal = 16;  // doubles per instance in the scratch `scal` record (test kernels / diagnostic stamps)
+
+// Diagnostic build only (-DSDDP_STAMPS): per-phase shader-cycle sums, written to `scal`; never in the shipped library.
+#ifdef SDDP_STAMPS
+#define SDDP_T_DECL unsigned long long T_[kScal] = {0}; unsigned long long t_last_ = clock64();
+#define SDDP_T_ARG , unsigned long long* T_, unsigned long long& t_last_
+#define SDDP_T_PASS , T_, t_last_
+#define SDDP_TICK(i) { const unsigned long long t_ = clock64(); T_[i] += t_ - t_last_; t_last_ = t_; }
+#else
+#define SDDP_T_DECL
+#define SDDP_T_ARG
+#define SDDP_T_PASS
+#define SDDP_TICK(i)
+#endif
 
 struct SolveArgs {
     DevConsts c;
@@ -39,7 +53,7 @@ struct SolveArgs {
     double* gains;      // [B][N][NU*(NX+1)]  kff (NU) then K (NU x NX, row-major)
     double* rec;        // [B][N+1][NREC]
     sddp_stats* stats;  // [B]
-    double* scal;       // [B][8] (backward test kernel only)
+    double* scal;       // [B][kScal] (test kernels / diagnostic stamps)
     double alpha;       // forward test kernel only
     double mu;          // backward test kernel only
 };
@@ -128,7 +142,7 @@ __device__ __forceinline__ void phase_defects(const DevConsts& c, int N, const d
 template <class M>
 __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restrict__ P, const double* __restrict__ dft,
                                const double* __restrict__ rec, double* __restrict__ gains, double mu, double* s, int lane,
-                               double& dV1, double& G1, double& G2, double& qu_inf) {
+                               double& dV1, double& G1, double& G2, double& qu_inf SDDP_T_ARG) {
     using L = Lds<M>;
     constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NREC = M::NREC, NP = M::NP;
     constexpr int NCOL = NU + 1 + NX;
@@ -153,6 +167,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         for (int e = lane; e < NP; e += kWave) s[L::PK + e] = P[k * NP + e];
         if (lane < NX) s[L::DK + lane] = dft[k * NX + lane];
         __syncthreads();
+        SDDP_TICK(1)
         // ---- expand [fx fu], GN Hessian, gradient; v' = Vx + Vxx d ; gap terms
         for (int e = lane; e < NX * NZ; e += kWave) s[L::F + e] = M::F_entry(c, s + L::REC, e / NZ, e % NZ);
         for (int e = lane; e < NZ * NZ; e += kWave) s[L::Q + e] = M::H_entry(c, s + L::REC, s + L::PK, k, N, e / NZ, e % NZ);
@@ -169,6 +184,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         G1 += wave_sum(g1);
         G2 += wave_sum(g2);
         __syncthreads();
+        SDDP_TICK(2)
         // ---- W = Vxx [fx fu]
         for (int e = lane; e < NX * NZ; e += kWave) {
             const int i = e / NZ, j = e % NZ;
@@ -177,6 +193,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             s[L::W + e] = acc;
         }
         __syncthreads();
+        SDDP_TICK(3)
         // ---- Q = H + F^T W ; q = g + F^T v'
         for (int e = lane; e < NZ * NZ; e += kWave) {
             const int i = e / NZ, j = e % NZ;
@@ -190,6 +207,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             s[L::QV + e] = acc;
         }
         __syncthreads();
+        SDDP_TICK(4)
         // ---- [k K] = -Quu^-1 [Qu Qux]: Gauss-Jordan, lane j owns column j of [Quu+mu I | Qu | Qux]
         double a[NU];
         if (lane < NCOL) {
@@ -239,6 +257,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         }
         dV1 += __shfl(dv, NU, kWave);
         __syncthreads();
+        SDDP_TICK(5)
         if (!ok) return false;
         // ---- Vx = Qx + Qux^T kff ; Vxx = sym(Qxx + Qux^T K)
         if (lane < NX) {
@@ -265,6 +284,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             gk[e] = v;
         }
         __syncthreads();
+        SDDP_TICK(6)
     }
     return ok;
 }
@@ -347,6 +367,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
     double* rec = A.rec + size_t(b) * (N + 1) * NREC;
 
     double J = 0.0, gap = 0.0;
+    SDDP_T_DECL
     // ---- starting point
     if (o.initial_rollout) {
         J = rollout<M, true>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, lane);
@@ -365,12 +386,14 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
     if (!(fabs(J) < 1e300)) { status = 3; }
     else
         while (iters < o.max_iters) {
+            SDDP_TICK(9)
             phase_derivs<M>(A.c, N, xs, us, P, rec, lane);
             __syncthreads();
+            SDDP_TICK(0)
             double dV1, G1, G2, qu_inf;
             bool ok;
             while (true) {
-                ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, mu, s, lane, dV1, G1, G2, qu_inf);
+                ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, mu, s, lane, dV1, G1, G2, qu_inf SDDP_T_PASS);
                 if (ok) break;
                 mu = fmax(mu, 0.0) * 10.0 + o.mu_min;
                 if (mu > o.mu_max) break;
@@ -389,7 +412,9 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
                 double a = a_base;
                 for (int j = 0; j < lane; ++j) a *= o.line_search_decrease_factor;
                 const bool valid = a >= o.alpha_converge_threshold;
+                SDDP_TICK(9)
                 double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, 0, lane);
+                SDDP_TICK(8)
                 ++rollouts;
                 const double pred = a * A1 + a * a * B2 - a * rho * gap;
                 const double dphi = (Jl + rho * (1.0 - a) * gap) - (J + rho * gap);
@@ -432,6 +457,10 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
         for (int e = lane; e < (N + 1) * NX; e += kWave) xs0[e] = xs[e];
         for (int e = lane; e < N * NU; e += kWave) us0[e] = us[e];
     }
+#ifdef SDDP_STAMPS
+    SDDP_TICK(9)
+    if (lane == 0) for (int i = 0; i < kScal; ++i) A.scal[size_t(b) * kScal + i] = (double)T_[i];
+#endif
     if (lane == 0) {
         sddp_stats st;
         st.cost = J; st.alpha = alpha; st.gap = gap; st.mu = mu; st.expected = expected;
@@ -501,9 +530,10 @@ __global__ __launch_bounds__(kWave) void backward_kernel(SolveArgs A) {
     phase_derivs<M>(A.c, N, xs, us, P, rec, lane);
     __syncthreads();
     double dV1, G1, G2, qu_inf;
-    const bool ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, A.mu, s, lane, dV1, G1, G2, qu_inf);
+    SDDP_T_DECL
+    const bool ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, A.mu, s, lane, dV1, G1, G2, qu_inf SDDP_T_PASS);
     if (lane == 0) {
-        double* sc = A.scal + size_t(b) * 8;
+        double* sc = A.scal + size_t(b) * kScal;
         sc[0] = dV1; sc[1] = -0.5 * dV1; sc[2] = G1; sc[3] = G2; sc[4] = ok ? 1.0 : 0.0; sc[5] = A.mu; sc[6] = qu_inf; sc[7] = J;
     }
 }
@@ -518,7 +548,7 @@ __global__ __launch_bounds__(kWave) void forward_kernel(SolveArgs A) {
                                        A.xs + size_t(b) * (N + 1) * NX, A.us + size_t(b) * N * NU,
                                        A.dft + size_t(b) * N * NX, A.gains + size_t(b) * N * (NU * (NX + 1)),
                                        A.xn + size_t(b) * (N + 1) * NX, A.un + size_t(b) * N * NU, A.alpha, 0, lane);
-    if (lane == 0) A.scal[size_t(b) * 8] = J;
+    if (lane == 0) A.scal[size_t(b) * kScal] = J;
 }
 
 }  // namespace sddp
