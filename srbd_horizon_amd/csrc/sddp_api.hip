@@ -102,7 +102,9 @@ int launch_backward(sddp_handle* h, const SolveArgs& a) {
 }
 template <class M>
 int launch_forward(sddp_handle* h, const SolveArgs& a) {
-    hipLaunchKernelGGL(forward_kernel<M>, dim3(h->B), dim3(kWave), 0, h->stream, a);
+    auto kern = forward_kernel<M>;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<M>::BYTES));
+    hipLaunchKernelGGL(kern, dim3(h->B), dim3(kWave), Lds<M>::BYTES, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     return SDDP_OK;
 }

@@ -69,25 +69,51 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-// LDS tile layout of one instance (offsets in doubles)
+// LDS tile layout of one instance (offsets in doubles).  Tiles are stored so that every inner product of the sweep
+// runs over CONTIGUOUS, 16-byte aligned rows (ds_read_b128, two fp64 per load):
+//   VXX [NXP][NXP]  Vxx+ (symmetric; pad row/col zero)
+//   FT  [NZP][NIP]  F~^T : FT[j][l] = F~[l][j],  F~ = [fx fu ; Je]  (NX dynamics rows + NE extra residual rows)
+//   WT  [NZP][NIP]  (V~ F~)^T : WT[j][l<NX] = sum_m Vxx[l][m] F[m][j] ;  WT[j][NX+m] = lambda_m(k) * Je[m][j]
+//   Q   [NZP][NZP]  diag(D) + F~^T (V~ F~)   (symmetric, both triangles written)
 template <class M>
 struct Lds {
-    static constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ;
+    static constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NI = NX + NE;
+    static constexpr int NXP = (NX + 1) & ~1;
+    static constexpr int NIP = (NI + 1) & ~1;
+    static constexpr int NZP = (NZ + 3) & ~3;
+    static constexpr int NUP = (NU + 1) & ~1;
+    static constexpr int NRECP = (M::NREC + 1) & ~1;
+    static constexpr int NPP = (M::NP + 1) & ~1;
     static constexpr int VXX = 0;
-    static constexpr int VX = VXX + NX * NX;
-    static constexpr int VP = VX + NX;
-    static constexpr int DK = VP + NX;
-    static constexpr int F = DK + NX;
-    static constexpr int W = F + NX * NZ;
-    static constexpr int Q = W + NX * NZ;
-    static constexpr int QV = Q + NZ * NZ;
-    static constexpr int REC = QV + NZ;
-    static constexpr int PK = REC + M::NREC;
-    static constexpr int KT = PK + M::NP;          // [NU][NX+1]: kff | K
-    static constexpr int PIV = KT + NU * (NX + 1);
-    static constexpr int TOTAL = PIV + NU + 2;
+    static constexpr int FT = VXX + NXP * NXP;
+    static constexpr int WT = FT + NZP * NIP;
+    static constexpr int Q = WT + NZP * NIP;
+    static constexpr int VX = Q + NZP * NZP;
+    static constexpr int VP = VX + NXP;
+    static constexpr int DK = VP + NXP;
+    static constexpr int QV = DK + NXP;
+    static constexpr int REC = QV + NZP;
+    static constexpr int PK = REC + NRECP;
+    static constexpr int KT = PK + NPP;            // [NXP][NUP]: KT[c][i] = K[i][c]
+    static constexpr int KF = KT + NXP * NUP;      // kff [NUP]
+    static constexpr int PIV = KF + NUP;           // [NUP]
+    static constexpr int DS = PIV + NUP;           // constant diagonal, state part   [NZP]
+    static constexpr int DG = DS + NZP;            // constant diagonal, stage part   [NZP]
+    static constexpr int LS = DG + NZP;            // extra-row weights, state / stage [NE] each
+    static constexpr int LG = LS + ((NE + 1) & ~1);
+    static constexpr int KI = LG + ((NE + 1) & ~1);    // ints: dkind[NZP], dci[NZP], tri LUT
+    static constexpr int NBQ = NZP / 2, NTRIQ = NBQ * (NBQ + 1) / 2;
+    static constexpr int NBV = NXP / 2, NTRIV = NBV * (NBV + 1) / 2;
+    static constexpr int KI_INTS = 2 * NZP + NTRIQ + NTRIV;
+    static constexpr int RO = KI + (KI_INTS + 1) / 2;  // rollout staging: xs | us | p | gains | dft of one knot
+    static constexpr int RO_X = 0, RO_U = NXP, RO_P = RO_U + NUP, RO_G = RO_P + NPP, RO_D = RO_G + ((NU * (NX + 1) + 1) & ~1);
+    static constexpr int RO_N = RO_D + NXP;
+    static constexpr int TOTAL = RO + RO_N;
     static constexpr size_t BYTES = size_t(TOTAL) * sizeof(double);
 };
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2_t lds2(const double* p) { return *reinterpret_cast<const double2_t*>(p); }
 
 // -----------------------------------------------------------------------------------------------------------------
 // derivative phase: one lane per knot -> compact records in HBM/L2
@@ -137,45 +163,121 @@ __device__ __forceinline__ void phase_defects(const DevConsts& c, int N, const d
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// one-time (per kernel) constant tables in LDS: constant part of F~^T, diagonal tables, extra-row weights, block LUTs
+// -----------------------------------------------------------------------------------------------------------------
+template <class M>
+__device__ void sweep_tables(const DevConsts& c, double* s, int lane) {
+    using L = Lds<M>;
+    constexpr int NX = M::NX, NZ = M::NZ, NE = M::NE;
+    for (int e = lane; e < L::TOTAL; e += kWave) s[e] = 0.0;
+    __syncthreads();
+    for (int e = lane; e < M::NREC; e += kWave) s[L::REC + e] = 0.0;         // zero record -> constant part of F
+    __syncthreads();
+    for (int e = lane; e < NZ * NX; e += kWave) {
+        const int j = e / NX, i = e % NX;
+        s[L::FT + j * L::NIP + i] = M::F_entry(c, s + L::REC, i, j);
+    }
+    for (int e = lane; e < NZ * NE; e += kWave) {
+        const int j = e / NE, m = e % NE;
+        s[L::FT + j * L::NIP + NX + m] = M::E_const(c, m, j);
+    }
+    int* ki = reinterpret_cast<int*>(s + L::KI);
+    for (int i = lane; i < NZ; i += kWave) {
+        s[L::DS + i] = M::dg_state(c, i);
+        s[L::DG + i] = M::dg_stage(c, i);
+        ki[i] = M::dkind(i);
+        ki[L::NZP + i] = M::dci(i);
+    }
+    for (int m = lane; m < NE; m += kWave) {
+        s[L::LS + m] = M::lam_state(c, m);
+        s[L::LG + m] = M::lam_stage(c, m);
+    }
+    // lower-triangle block LUTs: t -> (ba << 8) | bc with ba >= bc
+    for (int t = lane; t < L::NTRIQ; t += kWave) {
+        int ba = 0;
+        while ((ba + 1) * (ba + 2) / 2 <= t) ++ba;
+        ki[2 * L::NZP + t] = (ba << 8) | (t - ba * (ba + 1) / 2);
+    }
+    for (int t = lane; t < L::NTRIV; t += kWave) {
+        int ba = 0;
+        while ((ba + 1) * (ba + 2) / 2 <= t) ++ba;
+        ki[2 * L::NZP + L::NTRIQ + t] = (ba << 8) | (t - ba * (ba + 1) / 2);
+    }
+    __syncthreads();
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // backward Riccati sweep.  Returns false when a Quu is not positive definite (caller bumps mu, ddp.py:34-35).
+// Requires sweep_tables() to have run in this kernel.  One knot per loop trip; the next knot's record / parameters /
+// defect are prefetched into registers while the current knot is processed.
 // -----------------------------------------------------------------------------------------------------------------
 template <class M>
 __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restrict__ P, const double* __restrict__ dft,
                                const double* __restrict__ rec, double* __restrict__ gains, double mu, double* s, int lane,
                                double& dV1, double& G1, double& G2, double& qu_inf SDDP_T_ARG) {
     using L = Lds<M>;
-    constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NREC = M::NREC, NP = M::NP;
+    constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NREC = M::NREC, NP = M::NP;
+    constexpr int NXP = L::NXP, NIP = L::NIP, NZP = L::NZP, NUP = L::NUP;
     constexpr int NCOL = NU + 1 + NX;
+    constexpr int RREC = (NREC + kWave - 1) / kWave;
     static_assert(NCOL <= kWave, "one lane per augmented column");
-    static_assert(NX <= kWave, "one lane per state row");
+    static_assert(NX <= kWave && NP <= kWave, "one lane per state row / parameter");
+    const int* ki = reinterpret_cast<const int*>(s + L::KI);
     dV1 = G1 = G2 = qu_inf = 0.0;
     bool ok = true;
-    // ---- terminal node: Vx = lx_N, Vxx = lxx_N (ddp.py:216-226)
+    // ---- terminal node: Vx = lx_N, Vxx = lxx_N = diag(D_state) + Je^T Lambda_state Je  (ddp.py:216-226)
     {
         const double* rN = rec + size_t(N) * NREC;
-        for (int e = lane; e < NREC; e += kWave) s[L::REC + e] = rN[e];
-        for (int e = lane; e < NP; e += kWave) s[L::PK + e] = P[N * NP + e];
+        if (lane < NXP) s[L::VX + lane] = lane < NX ? rN[M::REC_G + lane] : 0.0;
+        if (lane < NP) s[L::PK + lane] = P[N * NP + lane];
         __syncthreads();
-        for (int e = lane; e < NX * NX; e += kWave) s[L::VXX + e] = M::H_entry(c, s + L::REC, s + L::PK, N, N, e / NX, e % NX);
-        if (lane < NX) s[L::VX + lane] = s[L::REC + M::REC_G + lane];
+        for (int e = lane; e < NXP * NXP; e += kWave) {
+            const int a = e / NXP, b = e % NXP;
+            double v = 0.0;
+            if (a < NX && b < NX) {
+                for (int m = 0; m < NE; ++m) v += s[L::LS + m] * s[L::FT + a * NIP + NX + m] * s[L::FT + b * NIP + NX + m];
+                if (a == b) v += s[L::DS + a] + M::dparam(c, s + L::PK, ki[a], ki[NZP + a], 1.0, 0.0);
+            }
+            s[L::VXX + e] = v;
+        }
         __syncthreads();
     }
+    // ---- prefetch knot N-1
+    double r_rec[RREC], r_p = 0.0, r_d = 0.0;
+    {
+        const double* rk = rec + size_t(N - 1) * NREC;
+#pragma unroll
+        for (int t = 0; t < RREC; ++t) r_rec[t] = (lane + t * kWave < NREC) ? rk[lane + t * kWave] : 0.0;
+        if (lane < NP) r_p = P[(N - 1) * NP + lane];
+        if (lane < NX) r_d = dft[(N - 1) * NX + lane];
+    }
     for (int k = N - 1; k >= 0; --k) {
-        // ---- stage this knot (coalesced: one knot per wave-wide access)
-        const double* rk = rec + size_t(k) * NREC;
-        for (int e = lane; e < NREC; e += kWave) s[L::REC + e] = rk[e];
-        for (int e = lane; e < NP; e += kWave) s[L::PK + e] = P[k * NP + e];
-        if (lane < NX) s[L::DK + lane] = dft[k * NX + lane];
+        // ---- stage this knot from the prefetch registers; start the next knot's loads
+#pragma unroll
+        for (int t = 0; t < RREC; ++t)
+            if (lane + t * kWave < NREC) s[L::REC + lane + t * kWave] = r_rec[t];
+        if (lane < NP) s[L::PK + lane] = r_p;
+        if (lane < NXP) s[L::DK + lane] = lane < NX ? r_d : 0.0;
+        if (k > 0) {
+            const double* rk = rec + size_t(k - 1) * NREC;
+#pragma unroll
+            for (int t = 0; t < RREC; ++t) r_rec[t] = (lane + t * kWave < NREC) ? rk[lane + t * kWave] : 0.0;
+            if (lane < NP) r_p = P[(k - 1) * NP + lane];
+            if (lane < NX) r_d = dft[(k - 1) * NX + lane];
+        }
         __syncthreads();
         SDDP_TICK(1)
-        // ---- expand [fx fu], GN Hessian, gradient; v' = Vx + Vxx d ; gap terms
-        for (int e = lane; e < NX * NZ; e += kWave) s[L::F + e] = M::F_entry(c, s + L::REC, e / NZ, e % NZ);
-        for (int e = lane; e < NZ * NZ; e += kWave) s[L::Q + e] = M::H_entry(c, s + L::REC, s + L::PK, k, N, e / NZ, e % NZ);
-        for (int e = lane; e < NZ; e += kWave) s[L::QV + e] = s[L::REC + M::REC_G + e];
+        const double state = k >= 1 ? 1.0 : 0.0;
+        // ---- expand: variable entries of F~^T; v' = Vx + Vxx d ; gap terms
+        M::expand_var(c, s + L::REC, s + L::FT, NIP, lane);
         double g1 = 0.0, g2 = 0.0;
         if (lane < NX) {
             double acc = 0.0;
-            for (int j = 0; j < NX; ++j) acc += s[L::VXX + lane * NX + j] * s[L::DK + j];
+#pragma unroll
+            for (int m = 0; m < NXP; m += 2) {
+                const double2_t v = lds2(s + L::VXX + lane * NXP + m), d = lds2(s + L::DK + m);
+                acc += v.x * d.x + v.y * d.y;
+            }
             const double d = s[L::DK + lane], vx = s[L::VX + lane];
             s[L::VP + lane] = vx + acc;
             g1 = d * vx;
@@ -185,26 +287,78 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         G2 += wave_sum(g2);
         __syncthreads();
         SDDP_TICK(2)
-        // ---- W = Vxx [fx fu]
-        for (int e = lane; e < NX * NZ; e += kWave) {
-            const int i = e / NZ, j = e % NZ;
-            double acc = 0.0;
-            for (int l = 0; l < NX; ++l) acc += s[L::VXX + i * NX + l] * s[L::F + l * NZ + j];
-            s[L::W + e] = acc;
+        // ---- WT = (V~ F~)^T : 2 (l) x 4 (j) register blocks, inner product over the NX dynamics rows
+        for (int blk = lane; blk < (NXP / 2) * (NZP / 4); blk += kWave) {
+            const int l0 = 2 * (blk % (NXP / 2)), j0 = 4 * (blk / (NXP / 2));
+            double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < NXP; m += 2) {
+                const double2_t v0 = lds2(s + L::VXX + l0 * NXP + m), v1 = lds2(s + L::VXX + (l0 + 1) * NXP + m);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const double2_t f = lds2(s + L::FT + (j0 + jj) * NIP + m);
+                    a0[jj] += v0.x * f.x + v0.y * f.y;
+                    a1[jj] += v1.x * f.x + v1.y * f.y;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                double2_t w;
+                w.x = a0[jj];
+                w.y = (l0 + 1 < NX) ? a1[jj] : 0.0;
+                *reinterpret_cast<double2_t*>(s + L::WT + (j0 + jj) * NIP + l0) = w;
+            }
+        }
+        __syncthreads();
+        // extra rows: WT[j][NX+m] = lambda_m(k) * Je[m][j]   (after the block stores: slot NX may have been zeroed as a pad)
+        for (int e = lane; e < NZ * NE; e += kWave) {
+            const int j = e / NE, m = e % NE;
+            const double lam = state * s[L::LS + m] + s[L::LG + m];
+            s[L::WT + j * NIP + NX + m] = lam * s[L::FT + j * NIP + NX + m];
         }
         __syncthreads();
         SDDP_TICK(3)
-        // ---- Q = H + F^T W ; q = g + F^T v'
-        for (int e = lane; e < NZ * NZ; e += kWave) {
-            const int i = e / NZ, j = e % NZ;
-            double acc = s[L::Q + e];
-            for (int l = 0; l < NX; ++l) acc += s[L::F + l * NZ + i] * s[L::W + l * NZ + j];
-            s[L::Q + e] = acc;
+        // ---- Q = diag(D) + F~^T (V~ F~): lower-triangle 2x2 blocks, mirrored ; q = g + F^T v'
+        for (int t = lane; t < L::NTRIQ; t += kWave) {
+            const int code = ki[2 * NZP + t];
+            const int a0 = 2 * (code >> 8), c0 = 2 * (code & 255);
+            double q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+#pragma unroll
+            for (int l = 0; l < NIP; l += 2) {
+                const double2_t fa = lds2(s + L::FT + a0 * NIP + l), fb = lds2(s + L::FT + (a0 + 1) * NIP + l);
+                const double2_t wa = lds2(s + L::WT + c0 * NIP + l), wb = lds2(s + L::WT + (c0 + 1) * NIP + l);
+                q00 += fa.x * wa.x + fa.y * wa.y;
+                q01 += fa.x * wb.x + fa.y * wb.y;
+                q10 += fb.x * wa.x + fb.y * wa.y;
+                q11 += fb.x * wb.x + fb.y * wb.y;
+            }
+            if (a0 == c0) {   // diagonal block: add D, keep it exactly symmetric
+                const double d0 = state * s[L::DS + a0] + s[L::DG + a0] + M::dparam(c, s + L::PK, ki[a0], ki[NZP + a0], state, 1.0);
+                const double d1 = state * s[L::DS + a0 + 1] + s[L::DG + a0 + 1] + M::dparam(c, s + L::PK, ki[a0 + 1], ki[NZP + a0 + 1], state, 1.0);
+                q00 += d0;
+                q11 += (a0 + 1 < NZ) ? d1 : 0.0;
+                const double off = 0.5 * (q01 + q10);
+                q01 = q10 = off;
+            }
+            double2_t r0, r1;
+            r0.x = q00; r0.y = q01; r1.x = q10; r1.y = q11;
+            *reinterpret_cast<double2_t*>(s + L::Q + a0 * NZP + c0) = r0;
+            *reinterpret_cast<double2_t*>(s + L::Q + (a0 + 1) * NZP + c0) = r1;
+            if (a0 != c0) {
+                double2_t m0, m1;
+                m0.x = q00; m0.y = q10; m1.x = q01; m1.y = q11;
+                *reinterpret_cast<double2_t*>(s + L::Q + c0 * NZP + a0) = m0;
+                *reinterpret_cast<double2_t*>(s + L::Q + (c0 + 1) * NZP + a0) = m1;
+            }
         }
-        for (int e = lane; e < NZ; e += kWave) {
-            double acc = s[L::QV + e];
-            for (int l = 0; l < NX; ++l) acc += s[L::F + l * NZ + e] * s[L::VP + l];
-            s[L::QV + e] = acc;
+        for (int j = lane; j < NZ; j += kWave) {
+            double acc = s[L::REC + M::REC_G + j];
+#pragma unroll
+            for (int m = 0; m < NXP; m += 2) {
+                const double2_t f = lds2(s + L::FT + j * NIP + m), v = lds2(s + L::VP + m);
+                acc += f.x * ((m < NX) ? v.x : 0.0) + f.y * ((m + 1 < NX) ? v.y : 0.0);
+            }
+            s[L::QV + j] = acc;
         }
         __syncthreads();
         SDDP_TICK(4)
@@ -214,9 +368,9 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 double v;
-                if (lane < NU) v = s[L::Q + (NX + i) * NZ + NX + lane] + (i == lane ? mu : 0.0);
+                if (lane < NU) v = s[L::Q + (NX + i) * NZP + NX + lane] + (i == lane ? mu : 0.0);
                 else if (lane == NU) v = s[L::QV + NX + i];
-                else v = s[L::Q + (NX + i) * NZ + (lane - NU - 1)];
+                else v = s[L::Q + (NX + i) * NZP + (lane - NU - 1)];
                 a[i] = v;
             }
         } else {
@@ -244,10 +398,14 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             }
             __syncthreads();
         }
-        // a = Quu^-1 * column ; publish kff | K (negated)
-        if (lane >= NU && lane < NCOL) {
+        // a = Quu^-1 * column ; publish kff and K^T (negated)
+        if (lane == NU) {
 #pragma unroll
-            for (int i = 0; i < NU; ++i) s[L::KT + i * (NX + 1) + (lane - NU)] = -a[i];
+            for (int i = 0; i < NU; ++i) s[L::KF + i] = -a[i];
+        }
+        if (lane > NU && lane < NCOL) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) s[L::KT + (lane - NU - 1) * NUP + i] = -a[i];
         }
         // dV1 += kff . Qu   (dV2 = 1/2 kff^T Quu kff = -1/2 dV1 exactly, not accumulated separately)
         double dv = 0.0;
@@ -259,28 +417,52 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         __syncthreads();
         SDDP_TICK(5)
         if (!ok) return false;
-        // ---- Vx = Qx + Qux^T kff ; Vxx = sym(Qxx + Qux^T K)
+        // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + 1/2 (Qux^T K + K^T Qux): lower-triangle 2x2 blocks, mirrored
         if (lane < NX) {
             double acc = s[L::QV + lane];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) acc += s[L::Q + (NX + i) * NZ + lane] * s[L::KT + i * (NX + 1)];
+            for (int i = 0; i < NU; ++i) acc += s[L::Q + lane * NZP + NX + i] * s[L::KF + i];
             s[L::VX + lane] = acc;
         }
-        for (int e = lane; e < NX * NX; e += kWave) {
-            const int i = e / NX, j = e % NX;
-            double acc = s[L::Q + i * NZ + j] + s[L::Q + j * NZ + i];
+        for (int t = lane; t < L::NTRIV; t += kWave) {
+            const int code = ki[2 * NZP + L::NTRIQ + t];
+            const int a0 = 2 * (code >> 8), c0 = 2 * (code & 255);
+            double v00 = 0, v01 = 0, v10 = 0, v11 = 0;
 #pragma unroll
-            for (int l = 0; l < NU; ++l)
-                acc += s[L::Q + (NX + l) * NZ + i] * s[L::KT + l * (NX + 1) + 1 + j] +
-                       s[L::Q + (NX + l) * NZ + j] * s[L::KT + l * (NX + 1) + 1 + i];
-            s[L::VXX + e] = 0.5 * acc;
+            for (int i = 0; i < NU; ++i) {
+                const double qa = s[L::Q + a0 * NZP + NX + i], qb = s[L::Q + (a0 + 1) * NZP + NX + i];
+                const double qc = s[L::Q + c0 * NZP + NX + i], qd = s[L::Q + (c0 + 1) * NZP + NX + i];
+                const double ka = s[L::KT + a0 * NUP + i], kb = s[L::KT + (a0 + 1) * NUP + i];
+                const double kc = s[L::KT + c0 * NUP + i], kd = s[L::KT + (c0 + 1) * NUP + i];
+                v00 += qa * kc + qc * ka;
+                v01 += qa * kd + qd * ka;
+                v10 += qb * kc + qc * kb;
+                v11 += qb * kd + qd * kb;
+            }
+            v00 = s[L::Q + a0 * NZP + c0] + 0.5 * v00;
+            v01 = s[L::Q + a0 * NZP + c0 + 1] + 0.5 * v01;
+            v10 = s[L::Q + (a0 + 1) * NZP + c0] + 0.5 * v10;
+            v11 = s[L::Q + (a0 + 1) * NZP + c0 + 1] + 0.5 * v11;
+            if (a0 + 1 >= NX) { v10 = 0.0; v11 = 0.0; }
+            if (c0 + 1 >= NX) { v01 = 0.0; v11 = 0.0; }
+            if (a0 == c0) { const double off = 0.5 * (v01 + v10); v01 = v10 = off; }
+            double2_t r0, r1;
+            r0.x = v00; r0.y = v01; r1.x = v10; r1.y = v11;
+            *reinterpret_cast<double2_t*>(s + L::VXX + a0 * NXP + c0) = r0;
+            *reinterpret_cast<double2_t*>(s + L::VXX + (a0 + 1) * NXP + c0) = r1;
+            if (a0 != c0) {
+                double2_t m0, m1;
+                m0.x = v00; m0.y = v10; m1.x = v01; m1.y = v11;
+                *reinterpret_cast<double2_t*>(s + L::VXX + c0 * NXP + a0) = m0;
+                *reinterpret_cast<double2_t*>(s + L::VXX + (c0 + 1) * NXP + a0) = m1;
+            }
         }
-        // ---- gains to HBM/L2: kff (NU) then K (NU x NX) row-major
+        // ---- gains to HBM/L2: kff (NU) then K (NU x NX) row-major, one coalesced wave-wide store per 64 words
         double* gk = gains + size_t(k) * (NU * (NX + 1));
         for (int e = lane; e < NU * (NX + 1); e += kWave) {
             double v;
-            if (e < NU) v = s[L::KT + e * (NX + 1)];
-            else { const int i = (e - NU) / NX, j = (e - NU) % NX; v = s[L::KT + i * (NX + 1) + 1 + j]; }
+            if (e < NU) v = s[L::KF + e];
+            else { const int i = (e - NU) / NX, j = (e - NU) % NX; v = s[L::KT + j * NUP + i]; }
             gk[e] = v;
         }
         __syncthreads();
@@ -292,37 +474,65 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
 // -----------------------------------------------------------------------------------------------------------------
 // forward pass: one lane per step length.  Every lane rolls the whole horizon with its own alpha; the lane
 // `store_lane` also writes its trajectory to xn/un.  OPEN_LOOP: plain rollout of us (single-shooting start).
+// The knot's wave-uniform operands (x_k, u_k, p_k, gains_k, d_k) are fetched by ONE coalesced wave-wide load each,
+// staged in LDS and read back as broadcasts; the next knot is prefetched into registers meanwhile.
 // -----------------------------------------------------------------------------------------------------------------
 template <class M, bool OPEN_LOOP>
 __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
                           const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
                           const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
-                          double alpha, int store_lane, int lane) {
-    constexpr int NX = M::NX, NU = M::NU;
+                          double alpha, int store_lane, int lane, double* s) {
+    using L = Lds<M>;
+    constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = NU * (NX + 1), RG = (NG + kWave - 1) / kWave;
+    double* ro = s + L::RO;
     double x[NX];
+    if (lane < NX) ro[L::RO_X + lane] = x0[lane];
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = x0[i];
+    for (int i = 0; i < NX; ++i) x[i] = ro[L::RO_X + i];
+    __syncthreads();
+    double r_x = 0, r_u = 0, r_p = 0, r_d = 0, r_g[RG];
+    auto fetch = [&](int k) {
+        if (lane < NU) r_u = us[k * NU + lane];
+        if (lane < NP) r_p = P[k * NP + lane];
+        if (!OPEN_LOOP) {
+            if (lane < NX) { r_x = xs[k * NX + lane]; r_d = dft[k * NX + lane]; }
+            const double* gk = gains + size_t(k) * NG;
+#pragma unroll
+            for (int t = 0; t < RG; ++t) r_g[t] = (lane + t * kWave < NG) ? gk[lane + t * kWave] : 0.0;
+        }
+    };
+    fetch(0);
     double J = 0.0;
     const double oma = 1.0 - alpha;
     for (int k = 0; k < N; ++k) {
+        if (lane < NU) ro[L::RO_U + lane] = r_u;
+        if (lane < NP) ro[L::RO_P + lane] = r_p;
+        if (!OPEN_LOOP) {
+            if (lane < NX) { ro[L::RO_X + lane] = r_x; ro[L::RO_D + lane] = r_d; }
+#pragma unroll
+            for (int t = 0; t < RG; ++t)
+                if (lane + t * kWave < NG) ro[L::RO_G + lane + t * kWave] = r_g[t];
+        }
+        if (k + 1 < N) fetch(k + 1);
+        __syncthreads();
         double u[NU], xnext[NX];
         if (OPEN_LOOP) {
 #pragma unroll
-            for (int i = 0; i < NU; ++i) u[i] = us[k * NU + i];
+            for (int i = 0; i < NU; ++i) u[i] = ro[L::RO_U + i];
         } else {
             double dx[NX];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) dx[j] = x[j] - xs[k * NX + j];
-            const double* gk = gains + size_t(k) * (NU * (NX + 1));
+            for (int j = 0; j < NX; ++j) dx[j] = x[j] - ro[L::RO_X + j];
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                double acc = us[k * NU + i] + alpha * gk[i];
+                double acc = ro[L::RO_U + i] + alpha * ro[L::RO_G + i];
 #pragma unroll
-                for (int j = 0; j < NX; ++j) acc += gk[NU + i * NX + j] * dx[j];
+                for (int j = 0; j < NX; ++j) acc += ro[L::RO_G + NU + i * NX + j] * dx[j];
                 u[i] = acc;
             }
         }
-        J += M::step(c, x, u, P + k * M::NP, k, xnext);
+        J += M::step(c, x, u, ro + L::RO_P, k, xnext);
         if (lane == store_lane) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) xn[k * NX + i] = x[i];
@@ -334,14 +544,18 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
             for (int i = 0; i < NX; ++i) x[i] = xnext[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = xnext[i] - oma * dft[k * NX + i];
+            for (int i = 0; i < NX; ++i) x[i] = xnext[i] - oma * ro[L::RO_D + i];
         }
+        __syncthreads();
     }
-    J += M::term_cost(c, x, P + N * M::NP);
+    if (lane < NP) ro[L::RO_P + lane] = P[N * NP + lane];
+    __syncthreads();
+    J += M::term_cost(c, x, ro + L::RO_P);
     if (lane == store_lane) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[N * NX + i] = x[i];
     }
+    __syncthreads();
     return J;
 }
 
@@ -368,9 +582,10 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
 
     double J = 0.0, gap = 0.0;
     SDDP_T_DECL
+    sweep_tables<M>(A.c, s, lane);
     // ---- starting point
     if (o.initial_rollout) {
-        J = rollout<M, true>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, lane);
+        J = rollout<M, true>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, lane, s);
         __syncthreads();
         for (int e = lane; e < (N + 1) * NX; e += kWave) xs[e] = xn[e];
         for (int e = lane; e < N * NX; e += kWave) dft[e] = 0.0;
@@ -413,7 +628,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
                 for (int j = 0; j < lane; ++j) a *= o.line_search_decrease_factor;
                 const bool valid = a >= o.alpha_converge_threshold;
                 SDDP_TICK(9)
-                double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, 0, lane);
+                double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, 0, lane, s);
                 SDDP_TICK(8)
                 ++rollouts;
                 const double pred = a * A1 + a * a * B2 - a * rho * gap;
@@ -426,7 +641,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
                     J_win = __shfl(Jl, win, kWave);
                     if (win != 0) {
                         __syncthreads();
-                        rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, lane);
+                        rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, lane, s);
                         ++rollouts;
                     }
                     accepted = true;
@@ -526,6 +741,7 @@ __global__ __launch_bounds__(kWave) void backward_kernel(SolveArgs A) {
     double* gains = A.gains + size_t(b) * N * (NU * (NX + 1));
     double* rec = A.rec + size_t(b) * (N + 1) * NREC;
     double J, gap;
+    sweep_tables<M>(A.c, s, lane);
     phase_defects<M>(A.c, N, xs, us, P, dft, lane, J, gap);
     phase_derivs<M>(A.c, N, xs, us, P, rec, lane);
     __syncthreads();
@@ -540,6 +756,7 @@ __global__ __launch_bounds__(kWave) void backward_kernel(SolveArgs A) {
 
 template <class M>
 __global__ __launch_bounds__(kWave) void forward_kernel(SolveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double s[];
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP;
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= A.B) return;
@@ -547,7 +764,7 @@ __global__ __launch_bounds__(kWave) void forward_kernel(SolveArgs A) {
     const double J = rollout<M, false>(A.c, N, A.x0 + size_t(b) * NX, A.P + size_t(b) * (N + 1) * NP,
                                        A.xs + size_t(b) * (N + 1) * NX, A.us + size_t(b) * N * NU,
                                        A.dft + size_t(b) * N * NX, A.gains + size_t(b) * N * (NU * (NX + 1)),
-                                       A.xn + size_t(b) * (N + 1) * NX, A.un + size_t(b) * N * NU, A.alpha, 0, lane);
+                                       A.xn + size_t(b) * (N + 1) * NX, A.un + size_t(b) * N * NU, A.alpha, 0, lane, s);
     if (lane == 0) A.scal[size_t(b) * kScal] = J;
 }
 

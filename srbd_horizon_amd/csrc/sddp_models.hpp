@@ -606,6 +606,102 @@ struct SrbdModel {
         }
         return v;
     }
+    // -------------------------------------------------------------------------------------------------------------
+    // Branch-free tile expansion used by the Riccati sweep (DESIGN.md "Kernel design").
+    // The Gauss-Newton Hessian is written  H = diag(D) + Je^T Lambda Je : single-variable residuals go to the diagonal,
+    // every multi-variable residual row (wdot, rddot, rel_pos, relative-velocity penalty) is an EXTRA ROW of the
+    // augmented Jacobian F~ = [F ; Je] with its weight on the diagonal of V~ = blockdiag(Vxx+, Lambda), so that
+    // Q = diag(D) + F~^T V~ F~ needs no special cases.  Only the wdot rows (A) and the quaternion blocks vary per knot.
+    // -------------------------------------------------------------------------------------------------------------
+    static constexpr int NE = 6 + (CS ? 4 + NC : 0);   // wdot(3) rddot(3) [rel_pos(4) rel_vel(NC)]
+    static constexpr int NVAR = 28 + 3 * NA;           // per-knot variable entries: quaternion blocks + A
+
+    // constant entry of extra row m w.r.t. z_j (one-time table fill; variable wdot rows are 0 here)
+    __device__ static double E_const(const DevConsts& c, int m, int j) {
+        int cls, ci, ax;
+        decode(j, cls, ci, ax);
+        if (m < 3) return 0.0;
+        if (m < 6) return (cls == V_F && ax == m - 3) ? c.inv_ms : 0.0;                    // rddot rows   prb.py:200
+        if (!CS) return 0.0;
+        if (m < 10) {                                                                       // rel_pos rows prb.py:192-199
+            const int pair = (m - 6) / 2, comp = ((m - 6) % 2 == 0) ? 1 : 0;                // y first, then x
+            if (cls != V_C || ax != comp) return 0.0;
+            return ci == pair ? -1.0 : (ci == pair + 2 ? 1.0 : 0.0);
+        }
+        const int pair = (m - 10) / 2, comp = (m - 10) % 2;                                 // relative_vel rows prb.py:166-170
+        if (cls != V_CD || ax != comp) return 0.0;
+        return ci == 2 * pair ? 1.0 : (ci == 2 * pair + 1 ? -1.0 : 0.0);
+    }
+    __device__ static double lam_state(const DevConsts& c, int m) { return (CS && m >= 6 && m < 10) ? 2 * c.w_rel : 0.0; }
+    __device__ static double lam_stage(const DevConsts& c, int m) {
+        if (m < 6) return 2 * c.gq;
+        return (CS && m >= 10) ? 2 * c.w_pen : 0.0;
+    }
+    // diagonal of the Hessian: constant parts and the kind of parameter-dependent part (0 none, 1 orientation gain,
+    // 2 force switch, 3 contact-velocity switch)
+    __device__ static double dg_state(const DevConsts& c, int i) {
+        int cls, ci, ax;
+        decode(i, cls, ci, ax);
+        if (cls == V_R) return ax == 2 ? 2 * c.w_rz : 0.0;
+        if (cls == V_RD) return 2 * c.w_rd;
+        if (cls == V_W) return 2 * c.w_w;
+        return 0.0;
+    }
+    __device__ static double dg_stage(const DevConsts& c, int i) {
+        int cls, ci, ax;
+        decode(i, cls, ci, ax);
+        if (cls == V_C) return ax == 2 ? 2 * c.w_pen : 0.0;
+        if (cls == V_CDD) return 2 * c.gq;
+        if (cls == V_F) return 2 * c.w_f;
+        return 0.0;
+    }
+    __device__ static int dkind(int i) {
+        int cls, ci, ax;
+        decode(i, cls, ci, ax);
+        if (cls == V_O) return 1;
+        if (cls == V_F) return 2;
+        if (cls == V_CD && ax < 2) return 3;
+        return 0;
+    }
+    __device__ static int dci(int i) {
+        int cls, ci, ax;
+        decode(i, cls, ci, ax);
+        return ci;
+    }
+    // parameter-dependent diagonal term of one knot (branch-free: all candidates evaluated, one selected)
+    __device__ __forceinline__ static double dparam(const DevConsts& c, const double* p, int kind, int ci, double state, double stage) {
+        const double otg = p_otg(p);
+        const double n2 = p_oref(p, 0) * p_oref(p, 0) + p_oref(p, 1) * p_oref(p, 1) + p_oref(p, 2) * p_oref(p, 2) + p_oref(p, 3) * p_oref(p, 3);
+        const double sw = CS ? p[8 + 2 * ci] : p[17 + ci];
+        const double v1 = state * 2 * otg * otg * n2;
+        const double v2 = stage * 2 * c.w_sw * (1.0 - sw) * (1.0 - sw);
+        const double v3 = stage * 2 * c.w_pen * sw * sw;
+        return kind == 1 ? v1 : (kind == 2 ? v2 : (kind == 3 ? v3 : 0.0));
+    }
+    // per-knot variable entries of F~^T (FT[j*NIP + l] = F~[l][j]); branch-free index arithmetic, one entry per lane-step
+    __device__ __forceinline__ static void expand_var(const DevConsts& c, const double* rec, double* FT, int NIP, int lane) {
+        for (int e = lane; e < NVAR; e += 64) {
+            int row, col, row2 = -1;
+            double val, raw = 0.0;
+            if (e < 28) {
+                const int a = e / 7, t = e % 7;
+                row = XO + a;
+                const bool isq = t < 4;
+                col = isq ? XO + t : XW + (t - 4);
+                raw = rec[isq ? REC_JO + 4 * a + t : REC_JW + 3 * a + (t - 4)];
+            } else {
+                const int m = (e - 28) / NA, j = (e - 28) % NA;
+                row = XW + m;
+                row2 = NX + m;                                   // the same A entry is also extra row m (wdot residual)
+                col = zcol(j);
+                raw = rec[REC_A + m * NA + j];
+            }
+            val = (row == col ? 1.0 : 0.0) + c.dt * raw;
+            FT[col * NIP + row] = val;
+            if (row2 >= 0) FT[col * NIP + row2] = raw;
+        }
+    }
+
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -801,6 +897,60 @@ struct LipModel {
         }
         return v;
     }
+    // ---- branch-free expansion hooks (see SrbdModel): everything is constant, all couplings are extra rows
+    static constexpr int NE = 16;   // rxy(2) zmp(3) rddot(3) rel_pos(4) rel_vel(4)
+    __device__ static double E_const(const DevConsts& c, int m, int j) {
+        int cls, ci, ax;
+        decode(j, cls, ci, ax);
+        if (m < 2) { if (ax != m) return 0.0; return cls == V_R ? 1.0 : (cls == V_C ? -0.25 : 0.0); }           // prb.py:391
+        if (m < 5) { if (ax != m - 2) return 0.0; return cls == V_Z ? 1.0 : (cls == V_C ? -0.25 : 0.0); }       // prb.py:393
+        if (m < 8) { if (ax != m - 5) return 0.0; return cls == V_R ? c.eta2 : (cls == V_Z ? -c.eta2 : 0.0); }  // prb.py:317,:402
+        if (m < 12) {
+            const int pair = (m - 8) / 2, comp = ((m - 8) % 2 == 0) ? 1 : 0;
+            if (cls != V_C || ax != comp) return 0.0;
+            return ci == pair ? -1.0 : (ci == pair + 2 ? 1.0 : 0.0);
+        }
+        const int pair = (m - 12) / 2, comp = (m - 12) % 2;
+        if (cls != V_CD || ax != comp) return 0.0;
+        return ci == 2 * pair ? 1.0 : (ci == 2 * pair + 1 ? -1.0 : 0.0);
+    }
+    __device__ static double lam_state(const DevConsts& c, int m) { return m < 2 ? 2 * c.w_rxy : ((m >= 8 && m < 12) ? 2 * c.w_rel : 0.0); }
+    __device__ static double lam_stage(const DevConsts& c, int m) {
+        if (m < 2) return 0.0;
+        if (m < 5) return 2 * c.w_zmp;
+        if (m < 8) return 2 * c.gq;
+        return m >= 12 ? 2 * c.w_pen : 0.0;
+    }
+    __device__ static double dg_state(const DevConsts& c, int i) {
+        int cls, ci, ax;
+        decode(i, cls, ci, ax);
+        if (cls == V_R) return ax == 2 ? 2 * c.w_rz : 0.0;
+        if (cls == V_RD) return 2 * c.w_rd;
+        return 0.0;
+    }
+    __device__ static double dg_stage(const DevConsts& c, int i) {
+        int cls, ci, ax;
+        decode(i, cls, ci, ax);
+        if (cls == V_C) return ax == 2 ? 2 * c.w_pen : 0.0;
+        if (cls == V_CDD) return 2 * c.gq;
+        return 0.0;
+    }
+    __device__ static int dkind(int i) {
+        int cls, ci, ax;
+        decode(i, cls, ci, ax);
+        return (cls == V_CD && ax < 2) ? 3 : 0;
+    }
+    __device__ static int dci(int i) {
+        int cls, ci, ax;
+        decode(i, cls, ci, ax);
+        return ci;
+    }
+    __device__ __forceinline__ static double dparam(const DevConsts& c, const double* p, int kind, int ci, double state, double stage) {
+        const double sw = p[4 + 2 * ci];
+        return kind == 3 ? stage * 2 * c.w_pen * sw * sw : 0.0;
+    }
+    __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int) {}
+
 };
 
 using Srbd13 = SrbdModel<2, false>;
