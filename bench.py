@@ -38,6 +38,19 @@ def algorithmic_bytes(N, nx, nu, npar, iters, rollouts, B):
     return float(np.sum(iters) * it + np.sum(rollouts) * ro + B * io)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/<round>/pmc_summary.json,
+    collected with separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; gfx950 corrections applied there)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(N, budget_s=15.0):
     """The oracle (numpy float64 restatement, 1 core) timed on a bounded sample of the same workload."""
     from oracle import ddp as oddp, models as omodels
@@ -158,7 +171,7 @@ def main():
         "converged_frac": float(np.mean(st["converged"] == 1)), "mean_rollouts": float(np.mean(rollouts)),
         "iterations_per_s": world * float(np.sum(iters)) * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "solve_kernel<SrbdModel<2,false>>", "kernel_ms": kms,
+                     "traffic": pmc_traffic() if (B == 1024 and N == 30) else None, "kernel": "solve_kernel<SrbdModel<2,false>>", "kernel_ms": kms,
                      "algorithmic_bytes_per_launch": abytes},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
