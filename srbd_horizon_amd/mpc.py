@@ -1,0 +1,72 @@
+"""Receding-horizon MPC loop: the body of reference python/dsrbd_example.py:82-185 with ROS stripped.
+
+Per tick (dsrbd_example.py line numbers): setInitialState (:84) -> shift rdot_ref / w_ref / oref / orientation gain back by
+one node (:102-106, one slice move per parameter) -> assign the commanded velocity at node ns (:109-124) -> wpg.set(action)
+(:126-131) -> solve, timed (:134-136: this is the "ms/MPC-tick" metric) -> simulate one Euler step with the first input
+and renormalise the quaternion (:158-160).  The closed-loop simulator step runs through the same HIP model code as the solver
+(`sddp_eval_knots`), so there is no second implementation of the dynamics on the host.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from . import wpg as _wpg
+from .ddp import DDPSolver
+from .engine import eval_knots
+from .prb import SRBD13Problem, SRBDProblem
+
+# reference option set (dsrbd_example.py:55-58)
+EXAMPLE_OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
+
+
+class MpcLoop:
+    def __init__(self, model: str = "srbd37", ns: int = 20, T: float | None = None, opts: dict | None = None, robot=None):
+        T = ns * 0.05 if T is None else T                              # wpg hard-codes dt = 0.05 (wpg.py:20)
+        if model == "srbd37":
+            self.srbd = SRBDProblem()
+            self.srbd.createSRBDProblem(ns, T, robot)
+            contact_model = self.srbd.contact_model
+        elif model == "srbd13":
+            self.srbd = SRBD13Problem()
+            self.srbd.createSRBD13Problem(ns, T, robot)
+            contact_model = 1
+        else:
+            raise ValueError(model)
+        self.model, self.ns = model, ns
+        self.solver = DDPSolver(self.srbd.prb, opts=dict(EXAMPLE_OPTS if opts is None else opts))
+        self.state = self.srbd.getInitialState().astype(float)
+        c_init_z = float(self.srbd.initial_foot_position[0][2])
+        self.wpg = _wpg.steps_phase(self.srbd.f, self.srbd.c, self.srbd.cdot, c_init_z, self.srbd.c_ref, self.srbd.w_ref,
+                                    self.srbd.orientation_tracking_gain, self.srbd.cdot_switch, ns, number_of_legs=2,
+                                    contact_model=contact_model)
+        # warm start the first solve like dsrbd_example.py:61-68 computes it (x = state at every node, u = static input)
+        self.solver.set_x_warmstart(np.repeat(self.state[:, None], ns + 1, axis=1))
+        self.solver.set_u_warmstart(np.repeat(self.srbd.getStaticInput()[:, None], ns, axis=1))
+        self.solve_ms = []
+
+    def tick(self, motion: str = "standing", axes=(0.0, 0.0)):
+        s, ns = self.srbd, self.ns
+        self.solver.setInitialState(self.state)                                        # :84
+        for par in (s.rdot_ref, s.w_ref, s.oref, s.orientation_tracking_gain):         # :102-106
+            par.values[:, :ns] = par.values[:, 1:ns + 1]
+        a = 0.1 if motion == "standing" else 0.5                                       # :109-112
+        s.rdot_ref.assign([a * axes[0], a * axes[1], 0.0], nodes=ns)                   # :119-122
+        self.wpg.set({"walking": "step", "jumping": "jump"}.get(motion, "standing"))   # :126-131
+        t0 = time.perf_counter()                                                       # :134 tic()
+        converged = self.solver.solve()                                                # :135
+        self.solve_ms.append(1e3 * (time.perf_counter() - t0))                         # :136 toc()
+        sol = self.solver.getSolutionDict()                                            # :137
+        u0 = sol["u_opt"][:, 0]                                                        # :158
+        p0 = s.prb.parameter_matrix()[0]
+        f, _, _, _, _ = eval_knots(self.model, ns, [0], self.state[None], u0[None], p0[None], consts=s.prb.model_consts)
+        self.state = f[0].copy()                                                       # :159 Euler step (same HIP model)
+        self.state[3:7] /= np.linalg.norm(self.state[3:7])                             # :160
+        return converged, sol
+
+    def run(self, ticks: int, motion="walking", axes=(1.0, 0.0)):
+        out = []
+        for _ in range(ticks):
+            out.append(self.tick(motion, axes)[0])
+        return out

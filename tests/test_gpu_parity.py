@@ -257,3 +257,21 @@ def test_full_size_batch_properties():
         assert st["iters"][b] == r.iters
         assert np.max(np.abs(x[b] - r.xs)) <= 1e-4 and np.max(np.abs(u[b] - r.us)) <= 1e-4
         assert abs(st["cost"][b] - r.cost) <= 1e-6 * abs(r.cost)
+
+
+def test_receding_horizon_loop_runs_and_tracks():
+    """mpc.MpcLoop = the body of dsrbd_example.py:82-185 without ROS: a few walking ticks on the reference-faithful model
+    (ns = 20, T = 1 s as in dsrbd_example.py:30-31) and on the metric model."""
+    from srbd_horizon_amd.mpc import MpcLoop
+    for model, ns in (("srbd37", 20), ("srbd13", 30)):
+        loop = MpcLoop(model, ns)
+        flags = loop.run(6, motion="walking", axes=(1.0, 0.0))
+        sol = loop.solver.getSolutionDict()
+        assert sol["x_opt"].shape == (loop.solver.state_size, ns + 1) and sol["u_opt"].shape == (loop.solver.input_size, ns)
+        assert set(["r", "o", "rdot", "w", "f0", "f1"]).issubset(sol.keys())
+        assert sol["r"].shape == (3, ns + 1) and sol["f0"].shape == (3, ns)
+        assert np.all(np.isfinite(loop.state)) and abs(np.linalg.norm(loop.state[3:7]) - 1.0) < 1e-12
+        assert len(loop.solve_ms) == 6 and all(np.isfinite(loop.solve_ms))
+        assert loop.wpg.step_counter == 6
+        assert abs(loop.state[2] - 0.88) < 0.05                       # CoM height is tracked
+        np.testing.assert_allclose(sol["x_opt"][:, 0], loop.solver._x0[0], atol=0)   # node 0 is the measured state
