@@ -63,6 +63,20 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
     return v;
 }
+// value of lane `l` (compile-time constant after unrolling) broadcast to the wave through SGPRs: 2 x v_readlane_b32
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+// 1/x to fp64 accuracy: hardware estimate + 2 Newton steps (pivots are checked > 0 and finite before use)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, kWave));
@@ -380,23 +394,17 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         double qu_abs = 0.0, qu_save[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) { qu_save[i] = a[i]; qu_abs = fmax(qu_abs, fabs(a[i])); }
-        qu_inf = fmax(qu_inf, __shfl(qu_abs, NU, kWave));
+        qu_inf = fmax(qu_inf, readlane_d(qu_abs, NU));
+        // pivot column broadcast with v_readlane (through SGPRs): no LDS hand-off, no barrier inside the elimination
 #pragma unroll
         for (int p = 0; p < NU; ++p) {
-            if (lane == p) {
+            double pv[NU];
 #pragma unroll
-                for (int i = 0; i < NU; ++i) s[L::PIV + i] = a[i];
-            }
-            __syncthreads();
-            const double piv = s[L::PIV + p];
-            if (!(piv > 0.0) || !(piv < 1e300)) ok = false;
-            const double t = a[p] / piv;
+            for (int i = 0; i < NU; ++i) pv[i] = readlane_d(a[i], p);
+            if (!(pv[p] > 0.0) || !(pv[p] < 1e300)) ok = false;
+            const double t = a[p] * fast_rcp(pv[p]);
 #pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                if (i == p) a[i] = t;
-                else a[i] -= s[L::PIV + i] * t;
-            }
-            __syncthreads();
+            for (int i = 0; i < NU; ++i) a[i] = (i == p) ? t : fma(-pv[i], t, a[i]);
         }
         // a = Quu^-1 * column ; publish kff and K^T (negated)
         if (lane == NU) {
@@ -413,7 +421,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
 #pragma unroll
             for (int i = 0; i < NU; ++i) dv += -a[i] * qu_save[i];
         }
-        dV1 += __shfl(dv, NU, kWave);
+        dV1 += readlane_d(dv, NU);
         __syncthreads();
         SDDP_TICK(5)
         if (!ok) return false;
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
         __syncthreads();
     }
     double mu = o.mu0, rho = 0.0, alpha = 0.0, expected = 0.0;
-    int iters = 0, converged = 0, status = 1, rollouts = 0;
+    int iters = 0, converged = 0, status = 1, rollouts = 0, guess = 0;
     if (!(fabs(J) < 1e300)) { status = 3; }
     else
         while (iters < o.max_iters) {
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
                 for (int j = 0; j < lane; ++j) a *= o.line_search_decrease_factor;
                 const bool valid = a >= o.alpha_converge_threshold;
                 SDDP_TICK(9)
-                double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, 0, lane, s);
+                double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, guess, lane, s);
                 SDDP_TICK(8)
                 ++rollouts;
                 const double pred = a * A1 + a * a * B2 - a * rho * gap;
@@ -639,15 +647,17 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
                     const int win = __ffsll((long long)mask) - 1;
                     a_win = __shfl(a, win, kWave);
                     J_win = __shfl(Jl, win, kWave);
-                    if (win != 0) {
+                    if (win != guess) {   // the stored trajectory is last iteration's winning lane: re-run only when it moves
                         __syncthreads();
                         rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, lane, s);
                         ++rollouts;
                     }
+                    guess = win;
                     accepted = true;
                     break;
                 }
                 a_base = __shfl(a, kWave - 1, kWave) * o.line_search_decrease_factor;
+                guess = 0;
             }
             if (!accepted) { alpha = 0.0; converged = 1; status = 0; break; }  // alpha fell below alpha_converge_threshold
             alpha = a_win;
