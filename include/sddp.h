@@ -47,6 +47,8 @@ typedef struct sddp_options {
     double gap_tol;                     /* defect 1-norm below which the gaps count as closed */
     double mu_min;                      /* regularisation bump floor */
     double mu_max;                      /* give up above this */
+    int    second_order;                /* 1: add the exact bilinear-torque term v'.f_ux once full steps are accepted
+                                           (DESIGN.md section 2); 0: plain Gauss-Newton / iLQR sweep */
 } sddp_options;
 
 /* replaces what the reference bakes into the CasADi graphs from the URDF and the rosparam server

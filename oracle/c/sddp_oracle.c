@@ -254,7 +254,7 @@ static int chol(double* A, int n) {
 }
 
 static int backward(const consts_t* c, int N, const double* xs, const double* us, const double* P, const double* d, double mu,
-                    double* K /*N x NU x NX*/, double* kff /*N x NU*/, double* sc /*dV1,dV2,G1,G2*/) {
+                    double theta, double* K /*N x NU x NX*/, double* kff /*N x NU*/, double* sc /*dV1,dV2,G1,G2*/) {
     double Vx[NX], Vxx[NX * NX], g[NZ], H[NZ * NZ];
     cost_derivs(c, xs + N * NX, NULL, P + N * NP, N, g, H);
     for (int i = 0; i < NX; ++i) { Vx[i] = g[i]; for (int j = 0; j < NX; ++j) Vxx[i * NX + j] = H[i * NZ + j]; }
@@ -272,6 +272,16 @@ static int backward(const consts_t* c, int N, const double* xs, const double* us
         for (int a = 0; a < NZ; ++a) {
             double s = g[a]; for (int l = 0; l < NX; ++l) s += F[l * NZ + a] * vp[l]; q[a] = s;
             for (int b = 0; b < NZ; ++b) { double t = H[a * NZ + b]; for (int l = 0; l < NX; ++l) t += F[l * NZ + a] * W[l * NZ + b]; Q[a * NZ + b] = t; }
+        }
+        if (theta != 0.0) { /* exact bilinear-torque term: Qux[f_a][r_b] -= theta * s * skew(y)[a][b], y = I_w^-1 (dt v'_w) */
+            double R[9], M[9], Mi[9], lam[3], y[3], S[9];
+            quat_to_rot(xs + k * NX + 3, R); world_inertia(c, R, M); inv3(M, Mi);
+            for (int a = 0; a < 3; ++a) lam[a] = c->dt * vp[10 + a];
+            mv3(Mi, lam, y); skew(y, S);
+            for (int i = 0; i < 2; ++i) for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) {
+                const double v = -theta * c->lever * S[3 * a + b2];
+                Q[(NX + 3 * i + a) * NZ + b2] += v; Q[b2 * NZ + NX + 3 * i + a] += v;
+            }
         }
         double L[NU * NU], Quu[NU * NU];
         for (int i = 0; i < NU; ++i) for (int j = 0; j < NU; ++j) Quu[i * NU + j] = L[i * NU + j] = Q[(NX + i) * NZ + NX + j] + (i == j ? mu : 0.0);
@@ -316,7 +326,7 @@ static double forward(const consts_t* c, int N, const double* x0, const double* 
     return J + cost(c, xn + N * NX, NULL, P + N * NP, N);
 }
 
-/* opts: max_iters, alpha_0, alpha_converge_threshold, factor, beta, cost_reduction_ths, mu0, initial_rollout, gap_tol, mu_min, mu_max
+/* opts: max_iters, alpha_0, alpha_converge_threshold, factor, beta, cost_reduction_ths, mu0, initial_rollout, gap_tol, mu_min, mu_max, second_order
  * stats out: cost, iters, converged, alpha, gap, mu, status */
 int oracle_srbd13_solve(const double* cpack, int N, const double* x0, const double* P, double* xs, double* us, const double* o, double* stats) {
     consts_t c; unpack_consts(cpack, &c);
@@ -334,12 +344,18 @@ int oracle_srbd13_solve(const double* cpack, int N, const double* x0, const doub
     }
     double J = total_cost(&c, N, xs, us, P), gap = 0;
     for (int i = 0; i < N * NX; ++i) gap += fabs(d[i]);
-    double mu = mu0, rho = 0, alpha = 0;
+    double mu = mu0, rho = 0, alpha = 0, theta = 0;
+    const int second_order = (int)o[11];
     int iters = 0, converged = 0, status = 1;
     if (!isfinite(J)) status = 3;
     else while (iters < max_iters) {
         double sc[4]; int ok;
-        for (;;) { ok = backward(&c, N, xs, us, P, d, mu, K, kff, sc); if (ok) break; mu = fmax(mu, 0.0) * 10.0 + mu_min; if (mu > mu_max) break; }
+        for (;;) {
+            ok = backward(&c, N, xs, us, P, d, mu, theta, K, kff, sc);
+            if (ok) break;
+            if (theta != 0.0) { theta = 0.0; continue; }
+            mu = fmax(mu, 0.0) * 10.0 + mu_min; if (mu > mu_max) break;
+        }
         if (!ok) { status = 2; break; }
         const double expected = -(sc[0] + sc[1]);
         if (expected < ths && gap <= gap_tol) { converged = 1; status = 0; break; }
@@ -354,8 +370,12 @@ int oracle_srbd13_solve(const double* cpack, int N, const double* x0, const doub
             if (isfinite(Jn) && dphi <= beta * pred + slack) { accepted = 1; break; }
             a *= fac;
         }
-        if (!accepted) { converged = 1; status = 0; alpha = 0.0; break; }
+        if (!accepted) {
+            if (theta != 0.0) { theta = 0.0; continue; }
+            converged = 1; status = 0; alpha = 0.0; break;
+        }
         alpha = a;
+        theta = (second_order && a == a0) ? 1.0 : 0.0;
         const double dJ = J - Jn;
         memcpy(xs, xn, sizeof(double) * (size_t)(N + 1) * NX); memcpy(us, un, sizeof(double) * (size_t)N * NU);
         J = Jn;

@@ -29,7 +29,8 @@ def pack_consts(cst):
 def pack_opts(o):
     """o: oracle.ddp.DdpOptions"""
     return np.array([o.max_iters, o.alpha_0, o.alpha_converge_threshold, o.line_search_decrease_factor, o.beta,
-                     o.cost_reduction_ths, o.mu0, float(o.initial_rollout), o.gap_tol, o.mu_min, o.mu_max], dtype=np.float64)
+                     o.cost_reduction_ths, o.mu0, float(o.initial_rollout), o.gap_tol, o.mu_min, o.mu_max, float(o.second_order)],
+                    dtype=np.float64)
 
 
 def _p(a):

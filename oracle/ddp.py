@@ -8,6 +8,8 @@ steps; tests compare the two iteration by iteration.
 
     defects   d_{k+1} = f(x_k,u_k) - x_{k+1}
     backward  v' = Vx+ + Vxx+ d ; Q* = l* + F^T (.) ; Quu += mu I ; k = -Quu^-1 Qu ; K = -Quu^-1 Qux
+              second_order: Qux += theta * (v'.f_ux restricted to the bilinear torque (c-r) x f); theta = 1 after a full
+              step (alpha == alpha_0) was accepted, else 0; a failed sweep or line search with theta = 1 is redone with 0
               Vx = Qx + Qux^T k ; Vxx = Qxx + Qux^T K (symmetrised)
               dV1 = sum k^T Qu ; dV2 = 1/2 sum k^T Quu k ; G1 = sum d^T Vx+ ; G2 = 1/2 sum d^T Vxx+ d
     forward   xh_0 = x0 ; uh_k = u_k + a k_k + K_k (xh_k - x_k) ; xh_{k+1} = f(xh_k,uh_k) - (1-a) d_{k+1}
@@ -33,6 +35,7 @@ class DdpOptions:
     cost_reduction_ths: float = 1e-6          # ddp.py:32-33 (engine default unpinned)
     mu0: float = 0.0                          # ddp.py:34-35 (engine default unpinned)
     initial_rollout: bool = False             # True: single shooting (x warm start ignored)
+    second_order: bool = True                 # exact bilinear-torque term v'.f_ux once full steps are accepted
     gap_tol: float = 1e-9
     mu_min: float = 1e-6
     mu_max: float = 1e12
@@ -74,7 +77,7 @@ def rollout_open_loop(model, x0, us, P):
     return xs
 
 
-def backward_pass(model, xs, us, P, d, mu):
+def backward_pass(model, xs, us, P, d, mu, theta=0.0):
     """-> ok, K [N,nu,nx], kff [N,nu], dV1, dV2, G1, G2, Vx0, Vxx0, qu_inf"""
     N = us.shape[0]
     nx, nu = model.nx, model.nu
@@ -93,6 +96,8 @@ def backward_pass(model, xs, us, P, d, mu):
         Qu = lu + fu.T @ vp
         Qxx = lxx + fx.T @ Vxx @ fx
         Qux = lux + fu.T @ Vxx @ fx
+        if theta:
+            Qux = Qux + theta * model.second_order_ux(xs[k], us[k], P[k], vp)
         Quu = luu + fu.T @ Vxx @ fu + mu * np.eye(nu)
         try:
             L = np.linalg.cholesky(Quu)
@@ -140,6 +145,7 @@ def solve(model, x0, P, xs_ws, us_ws, opt: DdpOptions | None = None) -> DdpResul
     mu = opt.mu0
     rho = 0.0
     alpha = 0.0
+    theta = 0.0
     iters = 0
     converged = False
     status = 1
@@ -149,9 +155,12 @@ def solve(model, x0, P, xs_ws, us_ws, opt: DdpOptions | None = None) -> DdpResul
     while iters < opt.max_iters:
         # ---- backward sweep (regularisation bump on a non-PD Quu: this is what mu0 is for, ddp.py:34-35)
         while True:
-            ok, K, kff, dV1, dV2, G1, G2, Vx0, Vxx0, qu_inf = backward_pass(model, xs, us, P, d, mu)
+            ok, K, kff, dV1, dV2, G1, G2, Vx0, Vxx0, qu_inf = backward_pass(model, xs, us, P, d, mu, theta)
             if ok:
                 break
+            if theta:
+                theta = 0.0                       # second-order term made Quu indefinite: plain Gauss-Newton sweep
+                continue
             mu = max(mu, 0.0) * 10.0 + opt.mu_min
             if mu > opt.mu_max:
                 return DdpResult(xs, us, J, iters, False, alpha, gap, mu, 2, trace)
@@ -176,10 +185,14 @@ def solve(model, x0, P, xs_ws, us_ws, opt: DdpOptions | None = None) -> DdpResul
                 break
             a *= opt.line_search_decrease_factor
         if not accepted:
+            if theta:
+                theta = 0.0                       # redo this iteration with the plain Gauss-Newton step
+                continue
             converged, status = True, 0          # alpha fell below alpha_converge_threshold (App. C)
             alpha = 0.0
             break
         alpha = a
+        theta = 1.0 if (opt.second_order and a == opt.alpha_0) else 0.0
         dJ = J - Jn
         xs, us, J = xn, un, Jn
         d = (1.0 - a) * d
@@ -187,7 +200,7 @@ def solve(model, x0, P, xs_ws, us_ws, opt: DdpOptions | None = None) -> DdpResul
         iters += 1
         if mu > opt.mu0:
             mu = max(opt.mu0, mu * 0.1)
-        trace.append(dict(it=iters, cost=J, alpha=a, expected=expected, gap=gap, qu_inf=qu_inf, mu=mu, dJ=dJ))
+        trace.append(dict(it=iters, cost=J, alpha=a, expected=expected, gap=gap, qu_inf=qu_inf, mu=mu, dJ=dJ, theta=theta))
         if abs(dJ) < opt.cost_reduction_ths and gap <= opt.gap_tol:
             converged, status = True, 0
             break

@@ -210,6 +210,11 @@ class Model:
         r, Jx, Ju = self.residual_jac(x, u, p, k)
         return float(r @ r), 2 * Jx.T @ r, 2 * Ju.T @ r, 2 * Jx.T @ Jx, 2 * Ju.T @ Jx, 2 * Ju.T @ Ju
 
+    def second_order_ux(self, x, u, p, vp):
+        """Exact second-order dynamics term used by the DDP sweep: the (u, x) block of sum_i vp_i d2 f_i / du dx restricted to
+        the bilinear torque (c - r) x f of prb.py:99 (constant tensor).  Zero for linear models."""
+        return np.zeros((self.nu, self.nx))
+
     def initial_state(self):
         raise NotImplementedError
 
@@ -287,6 +292,14 @@ class SRBD13(Model):
             for i in range(2):
                 _force_rows(rows, c, fs[i], p[self.P_SW[i]], 3 * i)
         return rows.stack()
+
+    def second_order_ux(self, x, u, p, vp):
+        M, _ = world_inertia(self.cst, x[self.O_])
+        y = np.linalg.solve(M, self.cst.dt * vp[self.W_])
+        S = np.zeros((6, 13))
+        for i in range(2):
+            S[3 * i:3 * i + 3, self.R_] = -self.cst.lever_sign * skew(y)      # d2 (y.((c-r) x f)) / df dr
+        return S
 
     def initial_state(self):
         return np.concatenate([self.cst.com, [0, 0, 0, 1.0], np.zeros(6)])        # prb.py:224-240 reduced
@@ -461,6 +474,15 @@ class SRBD37(Model):
             _contact_penalty_rows(rows, cs, cds, [p[self.p_cref(i)] for i in range(4)],
                                   [p[self.p_sw(i)] for i in range(4)], self.C_IDX, self.CD_IDX, self.contact_model)
         return rows.stack()
+
+    def second_order_ux(self, x, u, p, vp):
+        M, _ = world_inertia(self.cst, x[self.O_])
+        y = np.linalg.solve(M, self.cst.dt * vp[self.W_])
+        S = np.zeros((24, 37))
+        for i in range(4):
+            S[6 * i + 3:6 * i + 6, self.R_] = -self.cst.lever_sign * skew(y)
+            S[6 * i + 3:6 * i + 6, self.C_IDX[i]:self.C_IDX[i] + 3] = self.cst.lever_sign * skew(y)
+        return S
 
     def initial_state(self):
         feet = np.asarray(self.cst.feet)

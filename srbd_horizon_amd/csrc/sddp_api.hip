@@ -164,6 +164,7 @@ void sddp_default_options(sddp_options* o) {
     o->gap_tol = 1e-9;
     o->mu_min = 1e-6;
     o->mu_max = 1e12;
+    o->second_order = 1;
 }
 
 void sddp_default_consts(sddp_model_consts* c) {

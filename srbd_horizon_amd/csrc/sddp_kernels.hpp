@@ -227,8 +227,8 @@ __device__ void sweep_tables(const DevConsts& c, double* s, int lane) {
 // -----------------------------------------------------------------------------------------------------------------
 template <class M>
 __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restrict__ P, const double* __restrict__ dft,
-                               const double* __restrict__ rec, double* __restrict__ gains, double mu, double* s, int lane,
-                               double& dV1, double& G1, double& G2, double& qu_inf SDDP_T_ARG) {
+                               const double* __restrict__ rec, double* __restrict__ gains, double mu, double theta, double* s,
+                               int lane, double& dV1, double& G1, double& G2, double& qu_inf SDDP_T_ARG) {
     using L = Lds<M>;
     constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NREC = M::NREC, NP = M::NP;
     constexpr int NXP = L::NXP, NIP = L::NIP, NZP = L::NZP, NUP = L::NUP;
@@ -375,6 +375,10 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             s[L::QV + j] = acc;
         }
         __syncthreads();
+        if (theta != 0.0) {   // exact second-order torque term (wave-uniform switch)
+            M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, NZP, theta, lane, kWave);
+            __syncthreads();
+        }
         SDDP_TICK(4)
         // ---- [k K] = -Quu^-1 [Qu Qux]: Gauss-Jordan, lane j owns column j of [Quu+mu I | Qu | Qux]
         double a[NU];
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
         phase_defects<M>(A.c, N, xs, us, P, dft, lane, J, gap);
         __syncthreads();
     }
-    double mu = o.mu0, rho = 0.0, alpha = 0.0, expected = 0.0;
+    double mu = o.mu0, rho = 0.0, alpha = 0.0, expected = 0.0, theta = 0.0;
     int iters = 0, converged = 0, status = 1, rollouts = 0, guess = 0;
     if (!(fabs(J) < 1e300)) { status = 3; }
     else
@@ -613,54 +617,62 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
             phase_derivs<M>(A.c, N, xs, us, P, rec, lane);
             __syncthreads();
             SDDP_TICK(0)
-            double dV1, G1, G2, qu_inf;
-            bool ok;
-            while (true) {
-                ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, mu, s, lane, dV1, G1, G2, qu_inf SDDP_T_PASS);
-                if (ok) break;
-                mu = fmax(mu, 0.0) * 10.0 + o.mu_min;
-                if (mu > o.mu_max) break;
-            }
-            if (!ok) { status = 2; break; }
-            const double dV2 = -0.5 * dV1;
-            expected = -(dV1 + dV2);
-            if (expected < o.cost_reduction_ths && gap <= o.gap_tol) { converged = 1; status = 0; break; }
-            const double A1 = dV1 + G1, B2 = dV2 + G2;
-            if (gap > 0.0) rho = fmax(rho, 2.0 * fmax(fmax(A1, A1 + B2), 0.0) / gap);
-            const double slack = 1e-13 * (fabs(J) + rho * gap);
-            // ---- line search: lane j tries alpha_0 * factor^j (the ladder of ddp.py:20-28 in one pass)
-            bool accepted = false;
-            double a_base = o.alpha_0, a_win = 0.0, J_win = 0.0;
-            while (a_base >= o.alpha_converge_threshold) {
-                double a = a_base;
-                for (int j = 0; j < lane; ++j) a *= o.line_search_decrease_factor;
-                const bool valid = a >= o.alpha_converge_threshold;
-                SDDP_TICK(9)
-                double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, guess, lane, s);
-                SDDP_TICK(8)
-                ++rollouts;
-                const double pred = a * A1 + a * a * B2 - a * rho * gap;
-                const double dphi = (Jl + rho * (1.0 - a) * gap) - (J + rho * gap);
-                const bool good = valid && (fabs(Jl) < 1e300) && (dphi <= o.beta * pred + slack);
-                const unsigned long long mask = __ballot(good);
-                if (mask) {
-                    const int win = __ffsll((long long)mask) - 1;
-                    a_win = __shfl(a, win, kWave);
-                    J_win = __shfl(Jl, win, kWave);
-                    if (win != guess) {   // the stored trajectory is last iteration's winning lane: re-run only when it moves
-                        __syncthreads();
-                        rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, lane, s);
-                        ++rollouts;
-                    }
-                    guess = win;
-                    accepted = true;
-                    break;
+            double dV1, G1, G2, qu_inf, a_win = 0.0, J_win = 0.0;
+            bool ok = true, stop = false, accepted = false;
+            do {   // at most twice: a failed sweep / line search with the second-order term is redone without it
+                while (true) {
+                    ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, mu, theta, s, lane, dV1, G1, G2, qu_inf SDDP_T_PASS);
+                    if (ok) break;
+                    if (theta != 0.0) { theta = 0.0; continue; }
+                    mu = fmax(mu, 0.0) * 10.0 + o.mu_min;
+                    if (mu > o.mu_max) break;
                 }
-                a_base = __shfl(a, kWave - 1, kWave) * o.line_search_decrease_factor;
-                guess = 0;
-            }
-            if (!accepted) { alpha = 0.0; converged = 1; status = 0; break; }  // alpha fell below alpha_converge_threshold
+                if (!ok) { status = 2; stop = true; break; }
+                const double dV2 = -0.5 * dV1;
+                expected = -(dV1 + dV2);
+                if (expected < o.cost_reduction_ths && gap <= o.gap_tol) { converged = 1; status = 0; stop = true; break; }
+                const double A1 = dV1 + G1, B2 = dV2 + G2;
+                if (gap > 0.0) rho = fmax(rho, 2.0 * fmax(fmax(A1, A1 + B2), 0.0) / gap);
+                const double slack = 1e-13 * (fabs(J) + rho * gap);
+                // ---- line search: lane j tries alpha_0 * factor^j (the ladder of ddp.py:20-28 in one pass)
+                accepted = false;
+                double a_base = o.alpha_0;
+                while (a_base >= o.alpha_converge_threshold) {
+                    double a = a_base;
+                    for (int j = 0; j < lane; ++j) a *= o.line_search_decrease_factor;
+                    const bool valid = a >= o.alpha_converge_threshold;
+                    SDDP_TICK(9)
+                    double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, guess, lane, s);
+                    SDDP_TICK(8)
+                    ++rollouts;
+                    const double pred = a * A1 + a * a * B2 - a * rho * gap;
+                    const double dphi = (Jl + rho * (1.0 - a) * gap) - (J + rho * gap);
+                    const bool good = valid && (fabs(Jl) < 1e300) && (dphi <= o.beta * pred + slack);
+                    const unsigned long long mask = __ballot(good);
+                    if (mask) {
+                        const int win = __ffsll((long long)mask) - 1;
+                        a_win = __shfl(a, win, kWave);
+                        J_win = __shfl(Jl, win, kWave);
+                        if (win != guess) {   // the stored trajectory is last iteration's winning lane: re-run only when it moves
+                            __syncthreads();
+                            rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, lane, s);
+                            ++rollouts;
+                        }
+                        guess = win;
+                        accepted = true;
+                        break;
+                    }
+                    a_base = __shfl(a, kWave - 1, kWave) * o.line_search_decrease_factor;
+                    guess = 0;
+                }
+                if (accepted) break;
+                if (theta != 0.0) { theta = 0.0; continue; }                       // redo with the plain Gauss-Newton step
+                alpha = 0.0; converged = 1; status = 0; stop = true;               // alpha fell below alpha_converge_threshold
+                break;
+            } while (true);
+            if (stop) break;
             alpha = a_win;
+            theta = (o.second_order && alpha == o.alpha_0) ? 1.0 : 0.0;
             const double dJ = J - J_win;
             J = J_win;
             __syncthreads();
@@ -757,7 +769,7 @@ __global__ __launch_bounds__(kWave) void backward_kernel(SolveArgs A) {
     __syncthreads();
     double dV1, G1, G2, qu_inf;
     SDDP_T_DECL
-    const bool ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, A.mu, s, lane, dV1, G1, G2, qu_inf SDDP_T_PASS);
+    const bool ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, A.mu, A.alpha, s, lane, dV1, G1, G2, qu_inf SDDP_T_PASS);
     if (lane == 0) {
         double* sc = A.scal + size_t(b) * kScal;
         sc[0] = dV1; sc[1] = -0.5 * dV1; sc[2] = G1; sc[3] = G2; sc[4] = ok ? 1.0 : 0.0; sc[5] = A.mu; sc[6] = qu_inf; sc[7] = J;

@@ -182,7 +182,7 @@ struct SrbdModel {
     // compact columns of A = d wdot / d z : r(0..2) o(3..6) w(7..9) [c(3NC)] f(3NC)
     static constexpr int AC = 10, AF = 10 + (CS ? 3 * NC : 0), NA = AF + 3 * NC;
     // derivative record of one knot
-    static constexpr int REC_A = 0, REC_JO = 3 * NA, REC_JW = REC_JO + 16, REC_G = REC_JW + 12, NREC = REC_G + NZ;
+    static constexpr int REC_A = 0, REC_JO = 3 * NA, REC_JW = REC_JO + 16, REC_MI = REC_JW + 12, REC_G = REC_MI + 9, NREC = REC_G + NZ;
 
     __device__ __forceinline__ static int uf(int i) { return CS ? 6 * i + 3 : 3 * i; }  // prb.py:66-68 interleaved
     // parameter layouts: srbd37 = creation order; srbd13 = App. A.7
@@ -433,6 +433,8 @@ struct SrbdModel {
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int j = 0; j < NA; ++j) rec[REC_A + a * NA + j] = A[a][j];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) rec[REC_MI + i] = q.Mi[i];      // I_w^-1, for the second-order torque term
             // quaternion-rate blocks: d odot / d o (4x4), d odot / d w (4x3)
             {
                 double Jo[16], Jw[12];
@@ -702,6 +704,29 @@ struct SrbdModel {
         }
     }
 
+    // exact second-order dynamics term of the DDP sweep: v'.f_ux restricted to the bilinear torque (c - r) x f
+    //   Qux[f_i,a][r_b] += -theta * s * skew(y)[a][b] ,  Qux[f_i,a][c_i,b] += +theta * s * skew(y)[a][b] ,  y = I_w^-1 (dt v'_w)
+    // (constant tensor; Q is kept symmetric: both triangles are updated)
+    static constexpr int NSO = 9 * NC * (CS ? 2 : 1);
+    __device__ __forceinline__ static void add_second_order(const DevConsts& c, const double* rec, const double* vp, double* Q,
+                                                            int NZP, double theta, int lane, int nlanes) {
+        for (int e = lane; e < NSO; e += nlanes) {
+            const int blk = e / 9, a = (e % 9) / 3, b = e % 3;
+            const int i = blk % NC;
+            const bool isc = blk >= NC;
+            const double l0 = c.dt * vp[XW], l1 = c.dt * vp[XW + 1], l2 = c.dt * vp[XW + 2];
+            const int yi = (a == b) ? 0 : 3 - a - b;                      // index of the y component in skew(y)[a][b], a != b
+            const double* mi = rec + REC_MI + 3 * yi;
+            const double y = mi[0] * l0 + mi[1] * l1 + mi[2] * l2;
+            const int d = (b - a + 3) % 3;                                // 2: +y , 1: -y , 0: diagonal (zero)
+            const double sk = d == 2 ? y : (d == 1 ? -y : 0.0);
+            const double val = theta * c.lever * (isc ? sk : -sk);
+            const int row = NX + uf(i) + a, col = isc ? XC + 3 * i + b : XR + b;
+            Q[row * NZP + col] += val;
+            Q[col * NZP + row] += val;
+        }
+    }
+
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -950,6 +975,7 @@ struct LipModel {
         return kind == 3 ? stage * 2 * c.w_pen * sw * sw : 0.0;
     }
     __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int) {}
+    __device__ __forceinline__ static void add_second_order(const DevConsts&, const double*, const double*, double*, int, double, int, int) {}
 
 };
 

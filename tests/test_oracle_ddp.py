@@ -62,7 +62,13 @@ def test_srbd_solve_properties():
     assert r.converged and r.gap == 0.0
     costs = [t["cost"] for t in r.trace]
     assert all(b <= a + 1e-9 * abs(a) for a, b in zip(costs[1:], costs[2:]))      # after the gaps close: monotone
-    assert r.trace[-1]["expected"] < 1e-4 and r.trace[-1]["qu_inf"] < r.trace[0]["qu_inf"] * 1e-4
+    # with the second-order torque term the tail is (near-)quadratic: the model predicts the last decreases almost exactly
+    assert r.trace[-1]["expected"] < 1.0 and r.trace[-1]["qu_inf"] < r.trace[0]["qu_inf"] * 1e-4
+    assert abs(r.trace[-1]["dJ"] / r.trace[-1]["expected"] - 1.0) < 0.05
+    # ... and it beats plain Gauss-Newton on the same instance
+    r_gn = oddp.solve(m, batch["x0"][0], batch["params"][0], batch["xs"][0], batch["us"][0],
+                      oddp.DdpOptions(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3, second_order=False))
+    assert r_gn.converged and abs(r_gn.cost - r.cost) <= 1e-9 * r.cost and r.iters <= r_gn.iters
     d = oddp.defects(m, r.xs, r.us, batch["params"][0])
     assert np.max(np.abs(d)) < 1e-12
     np.testing.assert_array_equal(r.xs[0], batch["x0"][0])

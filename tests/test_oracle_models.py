@@ -126,3 +126,27 @@ def test_terminal_cost_has_no_constraints_and_node0_no_state_cost():
     assert n_term == 1 + 4 + 3 + 3 + 4
     assert n0 == 18 + 4 * 6 + (2 + 2 + 4 * 3)
     assert nk == n0 + n_term
+
+
+@pytest.mark.parametrize("name,imode,lever", [("srbd13", 0, 1.0), ("srbd13", 1, -1.0), ("srbd37", 0, 1.0)])
+def test_second_order_torque_term_matches_finite_differences(name, imode, lever):
+    """second_order_ux = the (force, r) and (force, c) blocks of sum_i vp_i d2 f_i / du dx (the bilinear torque (c-r) x f):
+    central differences of the analytic Jacobian fu(x) give the same blocks."""
+    m = models.make_model(name, models.RobotConsts(inertia_mode=imode, lever_sign=lever))
+    rng = np.random.default_rng(9)
+    x, u, p = _rand_point(m, rng)
+    vp = rng.standard_normal(m.nx)
+    S = m.second_order_ux(x, u, p, vp)
+    h = 1e-6
+    T = np.zeros((m.nu, m.nx))                      # T[a, b] = sum_i vp_i d (fu[i, a]) / d x_b
+    for b in range(m.nx):
+        e = np.zeros(m.nx); e[b] = h
+        fu_p = m.f_jac(x + e, u, p)[1]
+        fu_m = m.f_jac(x - e, u, p)[1]
+        T[:, b] = vp @ ((fu_p - fu_m) / (2 * h))
+    cols = list(range(0, 3)) + ([] if name == "srbd13" else list(range(7, 19)))       # r (and c_i for srbd37)
+    rows = [i for i in range(m.nu) if (name == "srbd13" or i % 6 >= 3)]                # force rows
+    sub = np.ix_(rows, cols)
+    np.testing.assert_allclose(S[sub], T[sub], rtol=1e-5, atol=1e-6 * max(1.0, np.max(np.abs(T))))
+    mask = np.ones_like(S, dtype=bool); mask[sub] = False
+    assert np.all(S[mask] == 0.0)
