@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="MPC instances per GPU")
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -181,6 +182,28 @@ def main():
                      "traffic": pmc_traffic() if (B == 1024 and N == 30) else None, "kernel": "solve_kernel<SrbdModel<2,false>>", "kernel_ms": kms,
                      "algorithmic_bytes_per_launch": abytes},
     }
+    if rank == 0 and world == 1 and not args.no_pipelined:
+        # Extra (never `value`): two batches in flight on two HIP streams / two handles.  A batch ends with its slowest
+        # instance (1 % of the instances run to max_iters), so the SIMDs of finished instances idle unless the next batch
+        # is already resident -- this is how a fleet server would drive the engine.
+        engs, streams = [eng], [torch.cuda.current_stream()]
+        e2 = DdpEngine("srbd13", N, B, opts=opts)
+        s2 = torch.cuda.Stream()
+        e2.use_torch_stream(s2)
+        engs.append(e2); streams.append(s2)
+        def pstep(i):
+            e, st_ = engs[i % 2], streams[i % 2]
+            with torch.cuda.stream(st_):
+                e.set_initial_state_device(d_x0); e.set_x_warmstart_device(d_xs); e.set_u_warmstart_device(d_us)
+                e.solve_device(d_P)
+        for i in range(2):
+            pstep(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(2 * args.steps):
+            pstep(i)
+        torch.cuda.synchronize()
+        out["pipelined_2_streams_solves_per_s"] = 2 * args.steps * B / (time.perf_counter() - t1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ms / MPC tick, configs[1]: one instance, host-pointer call (PCIe included), cold start
         e1 = DdpEngine("srbd13", N, 1, opts=opts)
