@@ -216,6 +216,21 @@ def main():
             ticks.append(1e3 * (time.perf_counter() - t1))
         out["ms_per_mpc_tick_b1"] = {"median": float(np.median(ticks[5:])), "p99": float(np.percentile(ticks[5:], 99)),
                                      "iters": int(e1.stats["iters"][0]), "note": "B=1, seed 0, cold start, host-pointer sddp_solve (PCIe-inclusive)"}
+        # ms / MPC tick as SURVEY 8(d) defines it: receding-horizon loop (param shift + pack + solve + unpack + simulate),
+        # B = 1, warm-started from the previous tick, walking with a forward command; 20 warm-up + 200 timed ticks
+        from srbd_horizon_amd.mpc import MpcLoop
+        loop = MpcLoop("srbd13", N)
+        tick_ms, solve_ms, its = [], [], []
+        for i in range(220):
+            t1 = time.perf_counter()
+            loop.tick("walking", (1.0, 0.0))
+            tick_ms.append(1e3 * (time.perf_counter() - t1))
+            its.append(int(loop.solver.stats["iters"]))
+        out["ms_per_mpc_tick"] = {"median": float(np.median(tick_ms[20:])), "p99": float(np.percentile(tick_ms[20:], 99)),
+                                  "solve_median": float(np.median(loop.solve_ms[20:])), "mean_iters": float(np.mean(its[20:])),
+                                  "note": "srbd13 receding-horizon loop (mpc.MpcLoop = dsrbd_example.py:82-185 without ROS), B=1, "
+                                          "N=30, walking forward, warm start = previous solution, 200 ticks after 20 warm-up; "
+                                          "tick = shift + pack + sddp_solve (host pointers) + unpack + one simulator step"}
         # PCIe-inclusive batch rate (host-pointer C-ABI call: params in, x/u/stats out) -- reported, never `value`
         eng.set_initial_state(batch["x0"])
         t_host = []

@@ -22,7 +22,10 @@ EXAMPLE_OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
 
 
 class MpcLoop:
-    def __init__(self, model: str = "srbd37", ns: int = 20, T: float | None = None, opts: dict | None = None, robot=None):
+    def __init__(self, model: str = "srbd37", ns: int = 20, T: float | None = None, opts: dict | None = None, robot=None,
+                 warm_start: str = "shift"):
+        """warm_start: "shift" = previous solution advanced by one knot (last knot repeated),
+        "previous" = previous solution as is (what a stateful pyddp object would keep), "reset" = x0 repeated / static input."""
         T = ns * 0.05 if T is None else T                              # wpg hard-codes dt = 0.05 (wpg.py:20)
         if model == "srbd37":
             self.srbd = SRBDProblem()
@@ -35,6 +38,7 @@ class MpcLoop:
         else:
             raise ValueError(model)
         self.model, self.ns = model, ns
+        self.warm_start = warm_start
         self.solver = DDPSolver(self.srbd.prb, opts=dict(EXAMPLE_OPTS if opts is None else opts))
         self.state = self.srbd.getInitialState().astype(float)
         c_init_z = float(self.srbd.initial_foot_position[0][2])
@@ -63,6 +67,13 @@ class MpcLoop:
         f, _, _, _, _ = eval_knots(self.model, ns, [0], self.state[None], u0[None], p0[None], consts=s.prb.model_consts)
         self.state = f[0].copy()                                                       # :159 Euler step (same HIP model)
         self.state[3:7] /= np.linalg.norm(self.state[3:7])                             # :160
+        if self.warm_start == "shift":
+            x, u = sol["x_opt"], sol["u_opt"]
+            self.solver.set_x_warmstart(np.concatenate([x[:, 1:], x[:, -1:]], axis=1))
+            self.solver.set_u_warmstart(np.concatenate([u[:, 1:], u[:, -1:]], axis=1))
+        elif self.warm_start == "reset":
+            self.solver.set_x_warmstart(np.repeat(self.state[:, None], ns + 1, axis=1))
+            self.solver.set_u_warmstart(np.repeat(s.getStaticInput()[:, None], ns, axis=1))
         return converged, sol
 
     def run(self, ticks: int, motion="walking", axes=(1.0, 0.0)):
