@@ -9,7 +9,10 @@ A "step" is one pass of the hot path over one batch of synthetic input: B = 1024
 GPU (BASELINE configs[2]; 8 GPUs x 1024 = configs[3]), N = 30 knots, nx = 13, nu = 6, each solved from a cold
 warm start (x = x0 at every node, u = static input) to convergence with the reference example's solver options
 (dsrbd_example.py:55-58).  Inputs are resident in HBM before the timed region; a step = reset warm start (D2D) + the
-fused persistent solve kernel (+ the RCCL all-gather of the solution records when N > 1).  Weak scaling.
+fused persistent solve kernel (+ the RCCL all-gather of the solution records when N > 1).  Steps are issued round-robin on
+`--streams` (default 2) handles / HIP streams, i.e. two batches are in flight: a batch ends with its slowest instance and the
+SIMDs of finished instances would idle otherwise; `--streams 1` is strictly sequential (reported as an extra field).
+Weak scaling.
 
 Rank 0 prints ONE JSON line; `roofline` and `cpu_baseline` are defined in DESIGN.md ("Measurement").
 """
@@ -88,7 +91,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="MPC instances per GPU")
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipelined", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="batches in flight (handles on separate HIP streams)")
+    ap.add_argument("--no-sequential", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -109,61 +113,80 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    N, B = args.horizon, args.batch
+    N, B, S = args.horizon, args.batch, max(1, args.streams)
     nx, nu, npar = 13, 6, 19
     seeds = rank * B + np.arange(B)                        # instances are sharded contiguously across ranks
     batch = workload.make_batch("srbd13", N, seeds)
     opts = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsrbd_example.py:55-58
-    eng = DdpEngine("srbd13", N, B, opts=opts)
-    eng.use_torch_stream()                                 # kernels run on torch's current stream
-    eng.enable_timing(True)
     d_x0 = torch.from_numpy(batch["x0"]).to(dev)
     d_xs = torch.from_numpy(batch["xs"]).to(dev)
     d_us = torch.from_numpy(batch["us"]).to(dev)
     d_P = torch.from_numpy(batch["params"]).to(dev)
     rec_words = (N + 1) * nx + N * nu + 2                  # trajectory + (cost, iters)
-    if world > 1:
-        send = torch.empty((B, rec_words), dtype=torch.float64, device=dev)
-        gathered = torch.empty((world * B, rec_words), dtype=torch.float64, device=dev)
-    views = eng.fetch_device_views()
-
-    def step():
-        eng.set_initial_state_device(d_x0)
-        eng.set_x_warmstart_device(d_xs)
-        eng.set_u_warmstart_device(d_us)
-        eng.solve_device(d_P)
-        eng.synchronize()                                  # also latches the kernel's HIP-event duration
+    # S handles on S HIP streams: S batches in flight.  A batch ends with its slowest instance, so with one batch in flight
+    # the SIMDs of finished instances idle; a serving loop keeps the next batch resident.
+    engs, streams, views, sends, gathers = [], [], [], [], []
+    for i in range(S):
+        e = DdpEngine("srbd13", N, B, opts=opts)
+        st_ = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
+        e.use_torch_stream(st_)
+        e.enable_timing(True)
+        engs.append(e); streams.append(st_); views.append(e.fetch_device_views())
         if world > 1:
-            x, u, sf, si = views
-            send[:, :(N + 1) * nx] = x.reshape(B, -1)
-            send[:, (N + 1) * nx:(N + 1) * nx + N * nu] = u.reshape(B, -1)
-            send[:, -2] = sf[:, 0]                          # cost
-            send[:, -1] = si[:, 10].to(torch.float64)       # iters
-            dist.all_gather_into_tensor(gathered, send)   # RCCL over xGMI
-        return eng.last_kernel_ms()
+            sends.append(torch.empty((B, rec_words), dtype=torch.float64, device=dev))
+            gathers.append(torch.empty((world * B, rec_words), dtype=torch.float64, device=dev))
+    eng = engs[0]
+
+    def step(i, engines=None):
+        k = i % (len(engines) if engines else S)
+        e, st_ = engs[k], streams[k]
+        with torch.cuda.stream(st_):
+            e.set_initial_state_device(d_x0)
+            e.set_x_warmstart_device(d_xs)
+            e.set_u_warmstart_device(d_us)
+            e.solve_device(d_P)
+            if world > 1:
+                x, u, sf, si = views[k]
+                send = sends[k]
+                send[:, :(N + 1) * nx] = x.reshape(B, -1)
+                send[:, (N + 1) * nx:(N + 1) * nx + N * nu] = u.reshape(B, -1)
+                send[:, -2] = sf[:, 0]                          # cost
+                send[:, -1] = si[:, 10].to(torch.float64)       # iters
+                dist.all_gather_into_tensor(gathers[k], send)  # RCCL over xGMI
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    def timed(n_steps, engines=None):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(i, engines)
+        barrier()
+        return time.perf_counter() - t0
+
+    for i in range(max(args.warmup, 0)):
+        step(i)
     barrier()
-    t0 = time.perf_counter()
-    kern_ms = []
-    for _ in range(args.steps):
-        kern_ms.append(step())
-    barrier()
-    elapsed = time.perf_counter() - t0
+    for e in engs:
+        e.synchronize()
+        e.kernel_time_stats(reset=True)
+    elapsed = timed(args.steps)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ksum = kcnt = 0
+    for e in engs:
+        e.synchronize()
+        sm, n = e.kernel_time_stats(reset=True)
+        ksum += sm; kcnt += n
 
     x, u, st = eng.fetch()
     iters, rollouts = st["iters"].astype(np.int64), st["rollouts"].astype(np.int64)
-    kms = float(np.mean(kern_ms))
+    kms = ksum / max(kcnt, 1)
     abytes = algorithmic_bytes(N, nx, nu, npar, iters, rollouts, B)
     achieved = abytes / (kms * 1e-3) / 1e9
     out = {
@@ -174,6 +197,7 @@ def main():
                                "(BASELINE configs[2]; x8 GPUs = configs[3]), cold start, whole line-search ladder "
                                "(alpha=1..1e-12, 40 candidates) rolled out per iteration",
                    "batch_per_gpu": B, "horizon_N": N, "solver_opts": opts, "algorithm": "MS-DDP, Gauss-Newton Hessians",
+                   "batches_in_flight": S,
                    "collective": "all_gather(solution records) per step" if world > 1 else "none"},
         "mean_iters": float(np.mean(iters)), "max_iters_hit_frac": float(np.mean(st["status"] == 1)),
         "converged_frac": float(np.mean(st["converged"] == 1)), "mean_rollouts": float(np.mean(rollouts)),
@@ -182,28 +206,11 @@ def main():
                      "traffic": pmc_traffic() if (B == 1024 and N == 30) else None, "kernel": "solve_kernel<SrbdModel<2,false>>", "kernel_ms": kms,
                      "algorithmic_bytes_per_launch": abytes},
     }
-    if rank == 0 and world == 1 and not args.no_pipelined:
-        # Extra (never `value`): two batches in flight on two HIP streams / two handles.  A batch ends with its slowest
-        # instance (1 % of the instances run to max_iters), so the SIMDs of finished instances idle unless the next batch
-        # is already resident -- this is how a fleet server would drive the engine.
-        engs, streams = [eng], [torch.cuda.current_stream()]
-        e2 = DdpEngine("srbd13", N, B, opts=opts)
-        s2 = torch.cuda.Stream()
-        e2.use_torch_stream(s2)
-        engs.append(e2); streams.append(s2)
-        def pstep(i):
-            e, st_ = engs[i % 2], streams[i % 2]
-            with torch.cuda.stream(st_):
-                e.set_initial_state_device(d_x0); e.set_x_warmstart_device(d_xs); e.set_u_warmstart_device(d_us)
-                e.solve_device(d_P)
-        for i in range(2):
-            pstep(i)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(2 * args.steps):
-            pstep(i)
-        torch.cuda.synchronize()
-        out["pipelined_2_streams_solves_per_s"] = 2 * args.steps * B / (time.perf_counter() - t1)
+    if rank == 0 and world == 1 and S > 1 and not args.no_sequential:
+        # Extra: strictly one batch in flight (the next step starts after the previous one's slowest instance has finished)
+        el1 = timed(args.steps, engines=[eng])
+        out["one_batch_in_flight_solves_per_s"] = B * args.steps / el1
+        out["one_batch_in_flight_ms_per_step"] = 1e3 * el1 / args.steps
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ms / MPC tick, configs[1]: one instance, host-pointer call (PCIe included), cold start
         e1 = DdpEngine("srbd13", N, 1, opts=opts)

@@ -119,6 +119,8 @@ int  sddp_device_ptr(sddp_handle* h, int which, void** ptr, long long* bytes);
 /* average device time (ms) of the last `sddp_solve*` kernel launch measured with HIP events on the handle's stream */
 int  sddp_last_kernel_ms(sddp_handle* h, double* ms);
 int  sddp_enable_timing(sddp_handle* h, int on);
+/* sum and count of the solve-kernel durations (HIP events, one pair per launch) read at the last sddp_synchronize calls */
+int  sddp_kernel_time_stats(sddp_handle* h, double* sum_ms, long long* count, int reset);
 
 /* ---- building blocks exposed for parity tests (host pointers) ------------------------------------------------
  * The same device code the fused solve kernel uses, one phase at a time.

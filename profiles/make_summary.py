@@ -6,7 +6,7 @@ rnd, trace, pf, pw, psq, blog = sys.argv[1:7]
 out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), rnd)
 os.makedirs(out_dir, exist_ok=True)
 one = lambda d, pat: sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))[0]
-shutil.copy(one(trace, "*kernel_stats.csv"), os.path.join(out_dir, "kernel_stats_bench_steps5.csv"))
+shutil.copy(one(trace, "*kernel_stats.csv"), os.path.join(out_dir, "kernel_stats_bench.csv"))
 rows = lambda f: [r for r in csv.DictReader(open(f)) if "solve_kernel" in r["Kernel_Name"]]
 out = {}
 for d, name in ((pf, "FETCH_SIZE"), (pw, "WRITE_SIZE")):
@@ -27,8 +27,8 @@ out["SQ"] = {k: sum(v) / len(v) for k, v in sq.items()}
 f, w = out["FETCH_SIZE"]["mean"], out["WRITE_SIZE"]["mean"]
 out["traffic_bytes_per_launch"] = (2 * f + w) * 1024
 out["traffic_bytes_per_launch_uncorrected"] = (f + w) * 1024
-out["note"] = ("rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_* each in its own run) of `python3 bench.py --steps 2 --warmup 1 "
-               "--no-cpu-baseline --no-pipelined`; FETCH/WRITE_SIZE in KiB; gfx950 correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE "
+out["note"] = ("rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_* each in its own run) of `python3 bench.py --steps 4 --warmup 2 "
+               "--no-cpu-baseline --no-sequential` (two batches in flight, the bench default); FETCH/WRITE_SIZE in KiB; gfx950 correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE "
                "doubled (calibrated for 16 B/lane streams; this kernel reads 8 B/lane, so the uncorrected figure is also given). "
                "Kernel = solve_kernel<SrbdModel<2,false>>, B=1024, N=30.")
 json.dump(out, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1)
@@ -38,4 +38,4 @@ d = json.loads(line)
 print({k: d.get(k) for k in ("value", "ms_per_step", "mean_iters", "mean_rollouts", "converged_frac", "iterations_per_s",
                               "pcie_inclusive_solves_per_s", "pipelined_2_streams_solves_per_s")})
 print(d["roofline"]); print(d["cpu_baseline"]); print(d["ms_per_mpc_tick_b1"]); print(out["SQ"]); print(out["kernel"])
-print(open(os.path.join(out_dir, "kernel_stats_bench_steps5.csv")).read())
+print(open(os.path.join(out_dir, "kernel_stats_bench.csv")).read())

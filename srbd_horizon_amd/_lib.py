@@ -75,6 +75,7 @@ SYMBOLS = {
     "sddp_device_ptr": (C.c_int, [_vp, C.c_int, _P(_vp), _P(C.c_longlong)]),
     "sddp_last_kernel_ms": (C.c_int, [_vp, _P(C.c_double)]),
     "sddp_enable_timing": (C.c_int, [_vp, C.c_int]),
+    "sddp_kernel_time_stats": (C.c_int, [_vp, _P(C.c_double), _P(C.c_longlong), C.c_int]),
     "sddp_eval_knots": (C.c_int, [C.c_int, _P(SddpModelConsts), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sddp_backward": (C.c_int, [_vp, _vp, C.c_double, _vp, _vp]),
     "sddp_forward": (C.c_int, [_vp, _vp, C.c_double, _vp, _vp, _vp]),

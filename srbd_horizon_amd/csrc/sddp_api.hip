@@ -49,8 +49,10 @@ struct sddp_handle {
     sddp_stats* stats = nullptr;
     // timing
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double last_ms = 0.0;
+    std::vector<hipEvent_t> ev;     // pairs (start, stop), one pair per launch since the last synchronize
+    size_t pending = 0;            // launches whose events have not been read yet
+    double last_ms = 0.0, sum_ms = 0.0;
+    long long n_ms = 0;
     std::string err;
     bool have_x0 = false, have_xws = false, have_uws = false;
 
@@ -86,10 +88,23 @@ template <class M>
 int launch_solve(sddp_handle* h, const SolveArgs& a) {
     auto kern = solve_kernel<M>;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<M>::BYTES));
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing) {
+        while (h->ev.size() < 2 * (h->pending + 1)) {
+            hipEvent_t e;
+            HIP_TRY(h, hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        e0 = h->ev[2 * h->pending];
+        e1 = h->ev[2 * h->pending + 1];
+        HIP_TRY(h, hipEventRecord(e0, h->stream));
+    }
     hipLaunchKernelGGL(kern, dim3(h->B), dim3(kWave), Lds<M>::BYTES, h->stream, a);
     HIP_TRY(h, hipGetLastError());
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    if (h->timing) {
+        HIP_TRY(h, hipEventRecord(e1, h->stream));
+        ++h->pending;
+    }
     return SDDP_OK;
 }
 template <class M>
@@ -223,8 +238,6 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (e == hipSuccess) e = hipMemset(h->stats, 0, size_t(batch) * sizeof(sddp_stats));
     if (e == hipSuccess) e = hipMemset(h->dft, 0, size_t(batch) * N * d.nx * D);
     if (e == hipSuccess) e = hipMemset(h->gains, 0, h->n_g() * D);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
         g_create_error = std::string("sddp_create: ") + hipGetErrorString(e);
         sddp_destroy(h);
@@ -240,8 +253,7 @@ void sddp_destroy(sddp_handle* h) {
     void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->dft, h->gains, h->rec, h->scal, h->stats};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -316,10 +328,15 @@ int sddp_solve_device(sddp_handle* h, const double* d_params) {
 int sddp_synchronize(sddp_handle* h) {
     if (!h) return SDDP_ERR_ARG;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->timing) {
+    for (size_t i = 0; i < h->pending; ++i) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_ms = ms;
+        if (hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]) == hipSuccess) {
+            h->last_ms = ms;
+            h->sum_ms += ms;
+            ++h->n_ms;
+        }
     }
+    h->pending = 0;
     return SDDP_OK;
 }
 
@@ -371,6 +388,13 @@ int sddp_enable_timing(sddp_handle* h, int on) {
 int sddp_last_kernel_ms(sddp_handle* h, double* ms) {
     if (!h || !ms) return SDDP_ERR_ARG;
     *ms = h->last_ms;
+    return SDDP_OK;
+}
+int sddp_kernel_time_stats(sddp_handle* h, double* sum_ms, long long* count, int reset) {
+    if (!h) return SDDP_ERR_ARG;
+    if (sum_ms) *sum_ms = h->sum_ms;
+    if (count) *count = h->n_ms;
+    if (reset) { h->sum_ms = 0.0; h->n_ms = 0; }
     return SDDP_OK;
 }
 

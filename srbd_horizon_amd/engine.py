@@ -139,6 +139,12 @@ class DdpEngine:
         self._chk(self.lib.sddp_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
 
+    def kernel_time_stats(self, reset=False):
+        """(sum_ms, count) of the solve-kernel durations measured with HIP events on the handle's stream."""
+        sm, n = C.c_double(), C.c_longlong()
+        self._chk(self.lib.sddp_kernel_time_stats(self.h, C.byref(sm), C.byref(n), int(reset)))
+        return sm.value, n.value
+
     def device_buffer(self, which: int):
         p, n = C.c_void_p(), C.c_longlong()
         self._chk(self.lib.sddp_device_ptr(self.h, which, C.byref(p), C.byref(n)))

@@ -5,7 +5,8 @@ Per instance ``seed``:
     phase ``seed mod 20`` and advanced ``N + 1 + seed mod 20`` ticks so the horizon is fully populated; the example
     loop's per-tick back-shift of rdot_ref / w_ref / oref / orientation gain (python/dsrbd_example.py:102-106) applied;
   * velocity command: rdot_ref = (0.5 a_x, 0.5 a_y, 0), a ~ U{-1,0,1}^2 (dsrbd_example.py:112, :119-122);
-  * footsteps (srbd13 only, contacts are data): each touchdown moves that foot by one stride = rdot_ref_xy * 1 s;
+  * footsteps (srbd13 only, contacts are data): each touchdown INSIDE the horizon moves that foot by one stride =
+    rdot_ref_xy * 1 s; at node 0 the feet are at their nominal places under the (perturbed) nominal initial state;
   * initial state: nominal + N(0, sigma) (1 cm, 5 cm/s, 0.05 rad/s, small-angle quaternion 0.02), renormalised;
   * warm start: x = x0 at every node, u = static input (what dsrbd_example.py:61-68 computes).
 
@@ -51,6 +52,7 @@ def _closed_form(N, seeds, init_z, init_sw, init_otg):
         td = ((prev == 0.0) & (sw_all == 1.0)).astype(float)
         cum = np.cumsum(td, axis=1)
         n_td[:, leg, :] = np.take_along_axis(cum, t - 1, axis=1)
+    n_td = n_td - n_td[:, :, :1]                         # count from node 0: the plan is relative to the current state
     return z, sw, otg, n_td
 
 
@@ -115,6 +117,9 @@ def schedule_by_ticking(N: int, seed: int, robot: RobotModel | None = None):
                 xy = xy + v * 1.0
             pb.c[i].values[0:2, N] = xy
             prev_sw[i] = sw_new
+    for i in range(2):                                    # the plan is relative to the current state (node 0 = nominal feet)
+        off = pb.c[i].values[0:2, 0] - pb.initial_foot_position[i][0:2]
+        pb.c[i].values[0:2, :] -= off[:, None]
     return pb.prb.parameter_matrix()
 
 
