@@ -1,6 +1,6 @@
 """Diagnostic: per-phase shader-cycle shares of the fused solve kernel (build with -DSDDP_STAMPS, SDDP_LIB=...)."""
-import ctypes as C, sys, numpy as np
-sys.path.insert(0, '.')
+import ctypes as C, os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from srbd_horizon_amd import workload, _lib
 from srbd_horizon_amd.engine import DdpEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

@@ -1,0 +1,89 @@
+"""Error behaviour and surface details of the drop-in boundary on a real device (C ABI status codes -> RuntimeError /
+ValueError / KeyError in the Python mirrors, like the reference's Python exceptions)."""
+import numpy as np
+import pytest
+
+from srbd_horizon_amd import workload
+from srbd_horizon_amd.ddp import DDPSolver
+from srbd_horizon_amd.engine import DdpEngine
+from srbd_horizon_amd.prb import LIPProblem, SRBD13Problem, SRBDProblem
+
+pytestmark = pytest.mark.gpu
+
+
+def test_engine_rejects_bad_calls():
+    eng = DdpEngine("srbd13", 30, 2)
+    batch = workload.make_batch("srbd13", 30, [0, 1])
+    with pytest.raises(RuntimeError, match="sddp_set_initial_state"):
+        eng.solve(batch["params"])                                   # nothing set yet
+    eng.set_initial_state(batch["x0"])
+    with pytest.raises(RuntimeError, match="u_warmstart"):
+        eng.solve(batch["params"])
+    with pytest.raises(ValueError):
+        eng.set_u_warmstart(batch["us"][:, :-1])                     # wrong shape
+    with pytest.raises(KeyError):
+        eng.set_options(not_an_option=1)
+    with pytest.raises(RuntimeError, match="line_search_decrease_factor"):
+        eng.set_options(line_search_decrease_factor=1.5)
+    with pytest.raises(KeyError):
+        DdpEngine("srbd13", 30, 1, opts=dict(bogus=1))
+    with pytest.raises(KeyError):
+        DdpEngine("no_such_model", 30, 1)
+    with pytest.raises(RuntimeError):
+        DdpEngine("srbd13", 0, 1)                                    # N < 1
+
+
+def test_non_finite_start_is_reported_not_propagated():
+    eng = DdpEngine("srbd13", 30, 2)
+    batch = workload.make_batch("srbd13", 30, [0, 1])
+    x0 = batch["x0"].copy()
+    x0[1, 3:7] = np.nan
+    xs = batch["xs"].copy()
+    xs[1, :, 3:7] = np.nan
+    eng.set_initial_state(x0); eng.set_x_warmstart(xs); eng.set_u_warmstart(batch["us"])
+    eng.solve(batch["params"])
+    assert eng.stats["status"][0] == 0 and eng.stats["converged"][0] == 1    # the healthy instance is unaffected
+    assert eng.stats["status"][1] == 3 and eng.stats["converged"][1] == 0 and eng.stats["iters"][1] == 0
+
+
+@pytest.mark.parametrize("builder,name,ns", [(SRBDProblem, "createSRBDProblem", 20), (LIPProblem, "createLIPProblem", 20),
+                                              (SRBD13Problem, "createSRBD13Problem", 30)])
+def test_ddpsolver_surface_matches_reference_adapter(builder, name, ns):
+    """Same surface as reference python/ddp.py: DDPSolver(prb, opts), setInitialState, solve() -> bool, getSolutionDict()
+    with one [dim, nodes] entry per variable plus 'x_opt' / 'u_opt' (ddp.py:102-104, :125-151)."""
+    pb = builder()
+    getattr(pb, name)(ns, ns * 0.05)
+    solver = DDPSolver(pb.prb, opts=dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3))
+    with pytest.raises(RuntimeError):
+        solver.solve()                                               # setInitialState first
+    x0 = pb.getInitialState()
+    solver.setInitialState(x0)
+    u_ws = np.repeat(pb.getStaticInput()[:, None], ns, axis=1)       # what dsrbd_example.py:61-68 computes
+    solver.set_u_warmstart(u_ws)
+    solver.set_x_warmstart(np.repeat(x0[:, None], ns + 1, axis=1))
+    assert solver.solve() is True
+    sol = solver.getSolutionDict()
+    nx, nu = solver.state_size, solver.input_size
+    assert sol["x_opt"].shape == (nx, ns + 1) and sol["u_opt"].shape == (nu, ns)
+    np.testing.assert_array_equal(sol["x_opt"][:, 0], x0)
+    names = [v.getName() for v in pb.prb.var_container.getVarList(offset=False)]
+    assert all(n in sol for n in names)
+    assert np.vstack([sol[n] for n in names if sol[n].shape[1] == ns + 1]).shape[0] == nx
+    assert np.vstack([sol[n] for n in names if sol[n].shape[1] == ns]).shape[0] == nu
+    # standing still at the nominal state is (nearly) optimal: the solution stays there
+    assert np.max(np.abs(sol["x_opt"] - x0[:, None])) < 0.25           # standing: the optimum stays near the nominal state
+    with pytest.raises(KeyError):
+        DDPSolver(pb.prb, opts=dict(max_iterations=5))               # unknown option key
+
+
+def test_default_warm_start_when_none_is_passed():
+    """The reference examples never pass a warm start: documented default x = x0 at every node, u = 0."""
+    pb = SRBD13Problem()
+    pb.createSRBD13Problem(30, 1.5)
+    solver = DDPSolver(pb.prb, opts=dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3))
+    solver.setInitialState(pb.getInitialState())
+    assert solver.solve() in (True, False)
+    assert np.all(np.isfinite(solver.getSolutionDict()["x_opt"]))
+    it1 = int(solver.stats["iters"])
+    solver.solve()                                                   # the solver object keeps its solution as warm start
+    assert int(solver.stats["iters"]) <= max(1, it1 // 2)
