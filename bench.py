@@ -107,11 +107,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DDP engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("SDDP_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 path on a 1-GPU box
+    if world > 1 and backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     N, B, S = args.horizon, args.batch, max(1, args.streams)
     nx, nu, npar = 13, 6, 19
