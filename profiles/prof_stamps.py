@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from srbd_horizon_amd import workload, _lib
 from srbd_horizon_amd.engine import DdpEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-N = 30
-batch = workload.make_batch("srbd13", N, np.arange(B))
-eng = DdpEngine("srbd13", N, B, opts=dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3))
+MODEL = sys.argv[2] if len(sys.argv) > 2 else "srbd13"
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+batch = workload.make_batch(MODEL, N, np.arange(B))
+eng = DdpEngine(MODEL, N, B, opts=dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3))
 eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
 eng.enable_timing(True)
 x, u = eng.solve(batch["params"])
