@@ -57,6 +57,14 @@ inline DevConsts make_dev_consts(const sddp_model_consts& c) {
     return d;
 }
 
+// Per-lane vector kept as an LDS column (element i of lane l at p[i*64 + l]): lets the wide models (srbd37) roll out without
+// 135 doubles of per-lane registers.  Reads/writes touch only the lane's own column: no bank conflict, no synchronisation.
+struct LdsCol {
+    double* p;
+    __device__ __forceinline__ double& operator[](int i) const { return p[i * 64]; }
+    __device__ __forceinline__ LdsCol operator+(int off) const { return LdsCol{p + off * 64}; }
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // small fixed-size helpers (all indices compile-time after unrolling -> registers)
 // ---------------------------------------------------------------------------------------------------------
@@ -222,8 +230,8 @@ struct SrbdModel {
         k.rddot[2] = fs[2] * c.inv_ms - kGravity;
     }
 
-    __device__ __forceinline__ static void load_contacts(const double* x, const double* u, const double* p,
-                                                         double (*cp)[3], double (*f)[3]) {
+    template <class XV, class UV>
+    __device__ __forceinline__ static void load_contacts(XV x, UV u, const double* p, double (*cp)[3], double (*f)[3]) {
 #pragma unroll
         for (int i = 0; i < NC; ++i)
 #pragma unroll
@@ -234,11 +242,12 @@ struct SrbdModel {
     }
 
     // cost of the state residuals (nodes 1..ns, prb.py:184-199)
-    __device__ __forceinline__ static double state_cost(const DevConsts& c, const double* x, const double* p) {
+    template <class XV>
+    __device__ __forceinline__ static double state_cost(const DevConsts& c, XV x, const double* p) {
         double L = 0;
         const double ez = x[XR + 2] - c.com_z;
         L += c.w_rz * ez * ez;
-        const double* o = x + XO;
+        const double o[4] = {x[XO], x[XO + 1], x[XO + 2], x[XO + 3]};
         const double qx = p_oref(p, 0), qy = p_oref(p, 1), qz = p_oref(p, 2), qw = p_oref(p, 3);
         const double e0 = o[3] * qx + qw * o[0] + (o[1] * qz - o[2] * qy);
         const double e1 = o[3] * qy + qw * o[1] + (o[2] * qx - o[0] * qz);
@@ -252,16 +261,16 @@ struct SrbdModel {
             L += c.w_rd * ed * ed + c.w_w * ew * ew;
         }
         if (CS) {
-            const double* c0 = x + XC; const double* c1 = x + XC + 3; const double* c2 = x + XC + 6; const double* c3 = x + XC + 9;
-            const double r1y = -c0[1] + c2[1] - c.d1y, r1x = -c0[0] + c2[0] - c.d1x;
-            const double r2y = -c1[1] + c3[1] - c.d2y, r2x = -c1[0] + c3[0] - c.d2x;
+            const double r1y = -x[XC + 1] + x[XC + 7] - c.d1y, r1x = -x[XC + 0] + x[XC + 6] - c.d1x;
+            const double r2y = -x[XC + 4] + x[XC + 10] - c.d2y, r2x = -x[XC + 3] + x[XC + 9] - c.d2x;
             L += c.w_rel * (r1y * r1y + r1x * r1x + r2y * r2y + r2x * r2x);
         }
         return L;
     }
 
     // cost of the input residuals + penalties given rddot/wdot (nodes 0..ns-1, prb.py:200-204, :166-181)
-    __device__ __forceinline__ static double input_cost(const DevConsts& c, const double* x, const double* u, const double* p,
+    template <class XV, class UV>
+    __device__ __forceinline__ static double input_cost(const DevConsts& c, XV x, UV u, const double* p,
                                                         const double (*f)[3], const Core& k) {
         double L = 0;
 #pragma unroll
@@ -275,8 +284,8 @@ struct SrbdModel {
         if (CS) {
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
-                const double* cdd = u + 6 * i;
-                L += c.gq * (cdd[0] * cdd[0] + cdd[1] * cdd[1] + cdd[2] * cdd[2]);
+                const double cdd0 = u[6 * i], cdd1 = u[6 * i + 1], cdd2 = u[6 * i + 2];
+                L += c.gq * (cdd0 * cdd0 + cdd1 * cdd1 + cdd2 * cdd2);
                 const double ez = x[XC + 3 * i + 2] - p_cref(p, i);
                 const double sw = p_sw(p, i);
                 const double vx = sw * x[XCD + 3 * i], vy = sw * x[XCD + 3 * i + 1];
@@ -292,12 +301,13 @@ struct SrbdModel {
     }
 
     // x+ = x + dt*xdot (explicit Euler, ddp.py:228-230) and L_k(x,u,p) (ddp.py:179-214) in one pass
-    __device__ __forceinline__ static double step(const DevConsts& c, const double* x, const double* u, const double* p,
-                                                  int k, double* xn) {
+    template <class XV, class UV, class XN>
+    __device__ __forceinline__ static double step(const DevConsts& c, XV x, UV u, const double* p, int k, XN xn) {
         double cp[NC][3], f[NC][3];
         load_contacts(x, u, p, cp, f);
         Core q;
-        const double* r = x + XR; const double* o = x + XO; const double* w = x + XW;
+        const double r[3] = {x[XR], x[XR + 1], x[XR + 2]}, o[4] = {x[XO], x[XO + 1], x[XO + 2], x[XO + 3]};
+        const double w[3] = {x[XW], x[XW + 1], x[XW + 2]};
         core(c, r, o, w, cp, f, q);
         double L = input_cost(c, x, u, p, f, q);
         if (k >= 1) L += state_cost(c, x, p);
@@ -324,7 +334,8 @@ struct SrbdModel {
         return L;
     }
 
-    __device__ __forceinline__ static double term_cost(const DevConsts& c, const double* x, const double* p) {
+    template <class XV>
+    __device__ __forceinline__ static double term_cost(const DevConsts& c, XV x, const double* p) {
         return state_cost(c, x, p);  // ddp.py:216-226: residuals only, no constraints
     }
 
