@@ -87,7 +87,7 @@ _lib = None
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/sddp_api.hip for gfx950 into libsddp_hip.so (in-tree, so it travels to the GPU box)."""
     src = os.path.join(CSRC, "sddp_api.hip")
-    deps = [src, os.path.join(CSRC, "sddp_kernels.hpp"), os.path.join(CSRC, "sddp_models.hpp"),
+    deps = [src, os.path.join(CSRC, "sddp_kernels.hpp"), os.path.join(CSRC, "sddp_kernels_mw.hpp"), os.path.join(CSRC, "sddp_models.hpp"),
             os.path.join(INCLUDE, "sddp.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH

@@ -11,6 +11,7 @@
 
 #include "sddp.h"
 #include "sddp_kernels.hpp"
+#include "sddp_kernels_mw.hpp"
 #include "sddp_models.hpp"
 
 using namespace sddp;
@@ -84,10 +85,17 @@ SolveArgs make_args(sddp_handle* h, const double* d_params) {
     return a;
 }
 
+// large models (> 48 KB of LDS per instance: srbd37, lip30) run on 4 waves per instance (sddp_kernels_mw.hpp)
+template <class M>
+constexpr bool use_mw() { return Lds<M>::BYTES > 48 * 1024; }
+
 template <class M>
 int launch_solve(sddp_handle* h, const SolveArgs& a) {
-    auto kern = solve_kernel<M>;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<M>::BYTES));
+    constexpr bool MW = use_mw<M>();
+    auto kern = MW ? solve_kernel_mw<M> : solve_kernel<M>;
+    constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
+    constexpr int threads = MW ? kThreadsMW : kWave;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         while (h->ev.size() < 2 * (h->pending + 1)) {
@@ -99,7 +107,7 @@ int launch_solve(sddp_handle* h, const SolveArgs& a) {
         e1 = h->ev[2 * h->pending + 1];
         HIP_TRY(h, hipEventRecord(e0, h->stream));
     }
-    hipLaunchKernelGGL(kern, dim3(h->B), dim3(kWave), Lds<M>::BYTES, h->stream, a);
+    hipLaunchKernelGGL(kern, dim3(h->B), dim3(threads), lds, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) {
         HIP_TRY(h, hipEventRecord(e1, h->stream));
@@ -109,9 +117,11 @@ int launch_solve(sddp_handle* h, const SolveArgs& a) {
 }
 template <class M>
 int launch_backward(sddp_handle* h, const SolveArgs& a) {
-    auto kern = backward_kernel<M>;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<M>::BYTES));
-    hipLaunchKernelGGL(kern, dim3(h->B), dim3(kWave), Lds<M>::BYTES, h->stream, a);
+    constexpr bool MW = use_mw<M>();
+    auto kern = MW ? backward_kernel_mw<M> : backward_kernel<M>;
+    constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(h->B), dim3(MW ? kThreadsMW : kWave), lds, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     return SDDP_OK;
 }

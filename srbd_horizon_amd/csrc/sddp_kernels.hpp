@@ -584,18 +584,19 @@ struct WideRollout {
     static constexpr bool enabled = (M::NX > 16) && (WORDS <= L::NZP * L::NIP + L::NZP * L::NZP);
 };
 
+// wt: the instance's WT tile (the columns run on into the Q tile behind it); no barrier inside
 template <class M, bool OPEN_LOOP>
-__device__ double rollout_lds(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
-                              const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
-                              const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
-                              double alpha, int store_lane, int lane, double* s) {
-    using L = Lds<M>;
+__device__ double rollout_lds_core(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
+                                   const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
+                                   const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
+                                   double alpha, int store_lane, int lane, double* wt SDDP_T_ARG) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = NU * (NX + 1);
-    const LdsCol X{s + L::WT + lane}, Y{s + L::WT + NX * kWave + lane}, U{s + L::WT + 2 * NX * kWave + lane};
+    const LdsCol X{wt + lane}, Y{wt + NX * kWave + lane}, U{wt + 2 * NX * kWave + lane};
     for (int i = 0; i < NX; ++i) X[i] = x0[i];
     double J = 0.0;
     const double oma = 1.0 - alpha;
     for (int k = 0; k < N; ++k) {
+        SDDP_TICK(8)
         if (OPEN_LOOP) {
             for (int i = 0; i < NU; ++i) U[i] = us[k * NU + i];
         } else {
@@ -610,11 +611,14 @@ __device__ double rollout_lds(const DevConsts& c, int N, const double* __restric
                 U[i] = acc;
             }
         }
+        SDDP_TICK(10)
         if (lane == store_lane) {
             for (int i = 0; i < NX; ++i) xn[k * NX + i] = X[i];
             for (int i = 0; i < NU; ++i) un[k * NU + i] = U[i];
         }
+        SDDP_TICK(11)
         J += M::step(c, X, U, P + k * NP, k, Y);                 // Y <- x+ (dx is no longer needed)
+        SDDP_TICK(12)
         if (OPEN_LOOP) {
             for (int i = 0; i < NX; ++i) X[i] = Y[i];
         } else {
@@ -625,6 +629,17 @@ __device__ double rollout_lds(const DevConsts& c, int N, const double* __restric
     if (lane == store_lane) {
         for (int i = 0; i < NX; ++i) xn[N * NX + i] = X[i];
     }
+    return J;
+}
+
+template <class M, bool OPEN_LOOP>
+__device__ double rollout_lds(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
+                              const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
+                              const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
+                              double alpha, int store_lane, int lane, double* s) {
+    using L = Lds<M>;
+    SDDP_T_DECL
+    const double J = rollout_lds_core<M, OPEN_LOOP>(c, N, x0, P, xs, us, dft, gains, xn, un, alpha, store_lane, lane, s + L::WT SDDP_T_PASS);
     __syncthreads();
     for (int e = lane; e < L::NZP * L::NIP; e += kWave) s[L::WT + e] = 0.0;   // restore the zero pads of the WT tile
     __syncthreads();

@@ -693,7 +693,10 @@ struct SrbdModel {
     }
     // per-knot variable entries of F~^T (FT[j*NIP + l] = F~[l][j]); branch-free index arithmetic, one entry per lane-step
     __device__ __forceinline__ static void expand_var(const DevConsts& c, const double* rec, double* FT, int NIP, int lane) {
-        for (int e = lane; e < NVAR; e += 64) {
+        expand_var(c, rec, FT, NIP, lane, 64);
+    }
+    __device__ __forceinline__ static void expand_var(const DevConsts& c, const double* rec, double* FT, int NIP, int tid, int nthreads) {
+        for (int e = tid; e < NVAR; e += nthreads) {
             int row, col, row2 = -1;
             double val, raw = 0.0;
             if (e < 28) {
@@ -986,6 +989,7 @@ struct LipModel {
         return kind == 3 ? stage * 2 * c.w_pen * sw * sw : 0.0;
     }
     __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int) {}
+    __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int, int) {}
     __device__ __forceinline__ static void add_second_order(const DevConsts&, const double*, const double*, double*, int, double, int, int) {}
 
 };

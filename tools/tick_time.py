@@ -1,0 +1,17 @@
+"""Per-tick solve time of the receding-horizon loop (MpcLoop) for one model: median / mean ms and iterations per tick."""
+import sys, time
+import numpy as np
+from srbd_horizon_amd.mpc import MpcLoop
+
+model = sys.argv[1] if len(sys.argv) > 1 else "srbd37"
+ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+loop = MpcLoop(model=model, ns=20)
+for _ in range(10):
+    loop.tick("walking", (1.0, 0.0))
+loop.solve_ms.clear()
+it = []
+for _ in range(ticks):
+    loop.tick("walking", (1.0, 0.0))
+    it.append(int(loop.solver.stats["iters"]))
+ms = np.array(loop.solve_ms)
+print(f"{model}: ms/tick median {np.median(ms):.3f} mean {ms.mean():.3f} max {ms.max():.3f} iters mean {np.mean(it):.2f}")
