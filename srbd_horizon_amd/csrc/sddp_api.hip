@@ -127,9 +127,11 @@ int launch_backward(sddp_handle* h, const SolveArgs& a) {
 }
 template <class M>
 int launch_forward(sddp_handle* h, const SolveArgs& a) {
-    auto kern = forward_kernel<M>;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<M>::BYTES));
-    hipLaunchKernelGGL(kern, dim3(h->B), dim3(kWave), Lds<M>::BYTES, h->stream, a);
+    constexpr bool MW = use_mw<M>();
+    auto kern = MW ? forward_kernel_mw<M> : forward_kernel<M>;
+    constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(h->B), dim3(MW ? kThreadsMW : kWave), lds, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     return SDDP_OK;
 }

@@ -1,53 +1,96 @@
 // sddp_kernels_mw.hpp -- the same DDP iteration as sddp_kernels.hpp for the LARGE models (srbd37: 37x37 / 61x61 tiles,
-// lip30), mapped on one 256-thread workgroup (4 wavefronts, one per SIMD of a CU) per MPC instance:
-//   * the tile phases of the Riccati sweep run one THREAD per tile element (the 1891 lower-triangle elements of Q at srbd37
-//     are 30 rounds of one wavefront but 8 rounds of four), separated by workgroup barriers;
-//   * wave 0 owns the scalar solver state and runs the lane-parallel phases (derivatives: lane per knot; line search: lane
-//     per step length, per-lane vectors in LDS columns; Quu Gauss-Jordan: lane per right-hand side); its decisions reach
-//     the other waves through the LDS control words CTL[1..2];
-//   * these models need > 48 KB of LDS per instance, i.e. at most two workgroups per CU, so the 4 waves do not fight the
-//     register budget that rules this mapping out for srbd13 at four instances per CU (experiment log).
-// Same device model code, same arithmetic, same parity tests as the single-wavefront kernel.
+// lip30), mapped on one 256-thread workgroup (4 wavefronts, one per SIMD of a CU) per MPC instance.
+//
+//   * Tile phases of the Riccati sweep: one THREAD per 3x3 / 3x4 / 2x2 register block of the output tile, operands read
+//     with ds_read_b128 from rows whose stride is == 2 (mod 4) doubles, so that the rows of a block column fall on 16
+//     distinct 16-byte LDS slots (MI355X_MICROARCH.md, LDS: b128 reads conflict per 16-lane group on (addr/4) mod 64).
+//   * Quu solve: block Gauss-Jordan across the 4 waves.  Lane j of every wave owns column j of [Quu + mu I | Qu | Qux];
+//     wave w owns rows [w RPW, (w+1) RPW).  Step b: wave b reduces its own rows (pivot column by v_readlane), publishes them
+//     in LDS, the other waves eliminate their rows against them: 4 hand-offs per knot instead of NU.
+//   * Forward pass (line search, one lane per step length): the feedback product u = u_k + alpha k + K (x - x_k) is split
+//     by rows over the 4 waves with the knot's gains staged in LDS (broadcast reads) and the per-lane vectors kept as LDS
+//     columns; the scalar model step runs in wave 0 while the other waves stage the next knot's gains.
+//   * Every wave keeps an identical copy of the scalar solver state (cost, merit weight, regularisation, counters); values
+//     produced by one wave only reach the others through the control words CTL[..] behind a workgroup barrier.
+//
+// These models need > 48 KB of LDS per instance (<= 2 workgroups per CU), so the 4 waves do not fight the register budget
+// that rules this mapping out for srbd13 at four instances per CU (experiment log).
+// Same device model code, same arithmetic up to summation order, same parity tests as the single-wavefront kernel.
 #pragma once
 #include "sddp_kernels.hpp"
 
 namespace sddp {
 
 constexpr int kThreadsMW = 256;
-constexpr int kLastWaveMW = kThreadsMW / kWave - 1;
+constexpr int kWavesMW = kThreadsMW / kWave;
+
+__host__ __device__ constexpr int pad2mod4(int n) { return ((n + 1) & ~3) + 2; }   // smallest m >= n with m == 2 (mod 4)
+__host__ __device__ constexpr int round_up(int n, int m) { return (n + m - 1) / m * m; }
+__host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 
 template <class M>
 struct LdsMW {
     static constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NI = NX + NE;
-    static constexpr int NXP = (NX + 1) & ~1;
-    static constexpr int NIP = (NI + 1) & ~1;
-    static constexpr int NZP = (NZ + 3) & ~3;
-    static constexpr int NUP = (NU + 1) & ~1;
-    static constexpr int NSTG = M::NREC + M::NP + NX;          // one knot's staged operands: record | params | defect
-    static constexpr int NSTGP = (NSTG + 1) & ~1;
+    // register-block shapes: W = (V~F~)^T in JW x LW blocks, Q in 3x3 lower-triangle blocks, Vxx in 2x2 lower-triangle blocks
+    static constexpr int JW = 3;
+    static constexpr int LW = (round_up(NZ, 3) / 3) * (round_up(NX, 3) / 3) <= kThreadsMW ? 3 : 4;
+    static constexpr int NJB = round_up(NZ, JW) / JW, NLB = round_up(NX, LW) / LW;
+    static constexpr int NBQ = round_up(NZ, 3) / 3, NTRIQ = NBQ * (NBQ + 1) / 2;
+    static constexpr int NBV = round_up(NX, 2) / 2, NTRIV = NBV * (NBV + 1) / 2;
+    // row strides (doubles), all == 2 (mod 4); row counts padded to the block shapes (pad rows stay zero)
+    static constexpr int SV = pad2mod4(NX), RV = round_up(NX, imax(LW, 2));     // VXX [RV][SV]
+    static constexpr int SI = pad2mod4(imax(NI, SV)), RZ = round_up(NZ, 3);     // FT, WT [RZ][SI]
+    static constexpr int SQ = pad2mod4(NZ), RQ = round_up(NZ, 2);               // Q [RQ][SQ]
+    static constexpr int SK = pad2mod4(NU);                                     // KT [NX][SK]: KT[c][i] = K[i][c]
+    static constexpr int RPW = (NU + kWavesMW - 1) / kWavesMW;                  // Gauss-Jordan rows per wave
+    static constexpr int NSTG = M::NREC + M::NP + NX;                           // staged knot: record | params | defect
+    static constexpr int NRECP = (M::NREC + 1) & ~1, NPP = (M::NP + 1) & ~1;
+    static constexpr int SG = (NX + 1) & ~1;                                    // staged gain rows in the forward pass
     static constexpr int VXX = 0;
-    static constexpr int FT = VXX + NXP * NXP;
-    static constexpr int WT = FT + NZP * NIP;                  // WT and Q are adjacent: the wide rollout's columns alias them
-    static constexpr int Q = WT + NZP * NIP;
-    static constexpr int VX = Q + NZP * NZP;
-    static constexpr int VP = VX + NXP;
-    static constexpr int QV = VP + NXP;
-    static constexpr int STG = QV + NZP;
-    static constexpr int REC = STG, PK = STG + M::NREC, DK = PK + M::NP;
-    static constexpr int KT = STG + NSTGP;             // [NXP][NUP]: KT[c][i] = K[i][c]
-    static constexpr int KF = KT + NXP * NUP;          // kff [NUP]
-    static constexpr int DS = KF + NUP;                // constant diagonal, state part   [NZP]
-    static constexpr int DG = DS + NZP;                // constant diagonal, stage part   [NZP]
-    static constexpr int LS = DG + NZP;                // extra-row weights, state / stage [NE] each
+    static constexpr int FT = VXX + RV * SV;
+    static constexpr int VX = FT + RZ * SI;
+    static constexpr int VP = VX + SV;
+    static constexpr int QV = VP + SV;
+    static constexpr int REC = QV + SQ;
+    static constexpr int PK = REC + NRECP;
+    static constexpr int DK = PK + NPP;                 // [SV], pad zero
+    static constexpr int KT = DK + SV;
+    static constexpr int KF = KT + NX * SK;            // kff [SK]
+    static constexpr int GT = KF + SK;                 // Gauss-Jordan hand-off rows, double buffered [2][RPW][64]
+    static constexpr int DS = GT + 2 * RPW * kWave;    // constant diagonal, state part [SQ]
+    static constexpr int DG = DS + SQ;                 // constant diagonal, stage part [SQ]
+    static constexpr int LS = DG + SQ;                 // extra-row weights, state / stage [NE] each
     static constexpr int LG = LS + ((NE + 1) & ~1);
-    static constexpr int CTL = LG + ((NE + 1) & ~1);   // control words shared by the 4 waves [8]
-    static constexpr int KI = CTL + 8;                 // ints: dkind[NZP], dci[NZP], lower-triangle element LUTs of Q and Vxx
-    static constexpr int NTRIQ = NZ * (NZ + 1) / 2, NTRIV = NX * (NX + 1) / 2;
-    static constexpr int KI_INTS = 2 * NZP + NTRIQ + NTRIV;
-    static constexpr int TOTAL = KI + (KI_INTS + 1) / 2;
+    static constexpr int CTL = LG + ((NE + 1) & ~1);   // control words shared by the 4 waves [16]
+    static constexpr int KI = CTL + 16;                // ints: dkind[SQ], dci[SQ], block LUTs of Q and Vxx
+    static constexpr int KI_INTS = 2 * SQ + NTRIQ + NTRIV;
+    static constexpr int WT = KI + ((KI_INTS + 1) / 2 + 1) / 2 * 2;
+    static constexpr int Q = WT + RZ * SI;
+    // forward pass: per-lane vector columns X | Y | U and the staged gains of one knot alias WT and Q (and may run past Q)
+    static constexpr int RO_X = WT, RO_Y = RO_X + NX * kWave, RO_U = RO_Y + NX * kWave, RO_G = RO_U + NU * kWave;
+    static constexpr int RO_K = RO_G + ((NU + 1) & ~1);                        // kff [NU] | K [NU][SG]
+    static constexpr int RO_END = RO_K + NU * SG;
+    static constexpr int TOTAL = imax(Q + RQ * SQ, RO_END);
     static constexpr size_t BYTES = size_t(TOTAL) * sizeof(double);
-    static constexpr bool WIDE = (NX > 16) && ((2 * NX + NU) * kWave <= NZP * NIP + NZP * NZP);
+    static_assert((FT | VX | VP | QV | REC | PK | DK | KT | KF | GT | DS | DG | LS | LG | CTL | KI | WT | Q | RO_G) % 2 == 0, "16-byte aligned sections");
 };
+
+// C[i][j] += sum_m A[i][m] B[j][m], m < 2 * K2: RA x RB register block, rows read two fp64 at a time
+template <int RA, int RB>
+__device__ __forceinline__ void dot_block(const double* A, int lda, const double* B, int ldb, int depth, double (&acc)[RA][RB]) {
+#pragma unroll 2
+    for (int m = 0; m < depth; m += 2) {
+        double2_t a[RA], b[RB];
+#pragma unroll
+        for (int i = 0; i < RA; ++i) a[i] = lds2(A + i * lda + m);
+#pragma unroll
+        for (int j = 0; j < RB; ++j) b[j] = lds2(B + j * ldb + m);
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+#pragma unroll
+            for (int j = 0; j < RB; ++j) acc[i][j] = fma(a[i].y, b[j].y, fma(a[i].x, b[j].x, acc[i][j]));
+    }
+}
 
 template <class M>
 __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
@@ -57,46 +100,47 @@ __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
     __syncthreads();
     for (int e = tid; e < NZ * NX; e += kThreadsMW) {
         const int j = e / NX, i = e % NX;
-        s[L::FT + j * L::NIP + i] = M::F_entry(c, s + L::REC, i, j);
+        s[L::FT + j * L::SI + i] = M::F_entry(c, s + L::REC, i, j);
     }
     for (int e = tid; e < NZ * NE; e += kThreadsMW) {
         const int j = e / NE, m = e % NE;
-        s[L::FT + j * L::NIP + NX + m] = M::E_const(c, m, j);
+        s[L::FT + j * L::SI + NX + m] = M::E_const(c, m, j);
     }
     int* ki = reinterpret_cast<int*>(s + L::KI);
     for (int i = tid; i < NZ; i += kThreadsMW) {
         s[L::DS + i] = M::dg_state(c, i);
         s[L::DG + i] = M::dg_stage(c, i);
         ki[i] = M::dkind(i);
-        ki[L::NZP + i] = M::dci(i);
+        ki[L::SQ + i] = M::dci(i);
     }
     for (int m = tid; m < NE; m += kThreadsMW) {
         s[L::LS + m] = M::lam_state(c, m);
         s[L::LG + m] = M::lam_stage(c, m);
     }
-    for (int t = tid; t < L::NTRIQ + L::NTRIV; t += kThreadsMW) {   // t -> (a << 8) | b with a >= b
+    for (int t = tid; t < L::NTRIQ + L::NTRIV; t += kThreadsMW) {   // t -> (block row << 8) | block column, row >= column
         const int tt = t < L::NTRIQ ? t : t - L::NTRIQ;
         int a = 0;
         while ((a + 1) * (a + 2) / 2 <= tt) ++a;
-        ki[2 * L::NZP + t] = (a << 8) | (tt - a * (a + 1) / 2);
+        ki[2 * L::SQ + t] = (a << 8) | (tt - a * (a + 1) / 2);
     }
     __syncthreads();
 }
 
-// backward Riccati sweep on 4 waves.  Returns false (to every thread) when a Quu is not positive definite.
-// dV1 / G1 / G2 / qu_inf are valid in wave 0 only.
+// backward Riccati sweep on 4 waves; every thread gets the same return value and the same dV1 / G1 / G2 / qu_inf.
 template <class M>
 __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __restrict__ P, const double* __restrict__ dft,
                                   const double* __restrict__ rec, double* __restrict__ gains, double mu, double theta,
                                   double* s, int tid, double& dV1, double& G1, double& G2, double& qu_inf SDDP_T_ARG) {
     using L = LdsMW<M>;
     constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NREC = M::NREC, NP = M::NP;
-    constexpr int NXP = L::NXP, NIP = L::NIP, NZP = L::NZP, NUP = L::NUP, NSTG = L::NSTG;
+    constexpr int SV = L::SV, SI = L::SI, SQ = L::SQ, SK = L::SK, NSTG = L::NSTG, RPW = L::RPW;
     constexpr int NCOL = NU + 1 + NX;
     constexpr int RS = (NSTG + kThreadsMW - 1) / kThreadsMW;
+    constexpr int kLast = kWavesMW - 1;
     static_assert(NCOL <= kWave, "one lane per augmented column");
     const int lane = tid & (kWave - 1), wave = tid / kWave;
     const int* ki = reinterpret_cast<const int*>(s + L::KI);
+    double g1_acc = 0.0, g2_acc = 0.0, dv_acc = 0.0, qu_acc = 0.0;   // per-wave partial sums, combined after the sweep
     dV1 = G1 = G2 = qu_inf = 0.0;
     auto stage_word = [&](int k, int w) -> double {    // [0,NREC) record | [NREC,NREC+NP) parameters | then the defect
         if (w < NREC) return rec[size_t(k) * NREC + w];
@@ -105,17 +149,15 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         return 0.0;
     };
     // ---- terminal node: Vx = lx_N, Vxx = lxx_N = diag(D_state) + Je^T Lambda_state Je  (ddp.py:216-226)
-    if (tid < NXP) s[L::VX + tid] = tid < NX ? rec[size_t(N) * NREC + M::REC_G + tid] : 0.0;
+    if (tid < SV) s[L::VX + tid] = tid < NX ? rec[size_t(N) * NREC + M::REC_G + tid] : 0.0;
     if (tid < NP) s[L::PK + tid] = P[N * NP + tid];
     __syncthreads();
-    for (int e = tid; e < NXP * NXP; e += kThreadsMW) {
-        const int a = e / NXP, b = e % NXP;
+    for (int e = tid; e < NX * NX; e += kThreadsMW) {
+        const int a = e / NX, b = e % NX;
         double v = 0.0;
-        if (a < NX && b < NX) {
-            for (int m = 0; m < NE; ++m) v += s[L::LS + m] * s[L::FT + a * NIP + NX + m] * s[L::FT + b * NIP + NX + m];
-            if (a == b) v += s[L::DS + a] + M::dparam(c, s + L::PK, ki[a], ki[NZP + a], 1.0, 0.0);
-        }
-        s[L::VXX + e] = v;
+        for (int m = 0; m < NE; ++m) v += s[L::LS + m] * s[L::FT + a * SI + NX + m] * s[L::FT + b * SI + NX + m];
+        if (a == b) v += s[L::DS + a] + M::dparam(c, s + L::PK, ki[a], ki[SQ + a], 1.0, 0.0);
+        s[L::VXX + a * SV + b] = v;
     }
     double r_stage[RS];
 #pragma unroll
@@ -124,8 +166,12 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
     for (int k = N - 1; k >= 0; --k) {
         // ---- stage this knot from the prefetch registers; start the next knot's loads
 #pragma unroll
-        for (int t = 0; t < RS; ++t)
-            if (tid + t * kThreadsMW < NSTG) s[L::STG + tid + t * kThreadsMW] = r_stage[t];
+        for (int t = 0; t < RS; ++t) {
+            const int w = tid + t * kThreadsMW;
+            if (w < NREC) s[L::REC + w] = r_stage[t];
+            else if (w < NREC + NP) s[L::PK + w - NREC] = r_stage[t];
+            else if (w < NSTG) s[L::DK + w - NREC - NP] = r_stage[t];
+        }
         if (k > 0) {
 #pragma unroll
             for (int t = 0; t < RS; ++t) r_stage[t] = stage_word(k - 1, tid + t * kThreadsMW);
@@ -133,126 +179,191 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         __syncthreads();
         SDDP_TICK(1)
         const double state = k >= 1 ? 1.0 : 0.0;
-        // ---- expand the variable entries of F~^T (all threads) ; v' = Vx + Vxx d and the gap terms (wave 0)
-        M::expand_var(c, s + L::REC, s + L::FT, NIP, tid, kThreadsMW);
-        if (wave == 0) {
-            double g1 = 0.0, g2 = 0.0;
-            if (lane < NX) {
-                double acc = 0.0;
-                for (int m = 0; m < NX; ++m) acc += s[L::VXX + lane * NXP + m] * s[L::DK + m];
-                const double d = s[L::DK + lane], vx = s[L::VX + lane];
-                s[L::VP + lane] = vx + acc;
-                g1 = d * vx;
-                g2 = 0.5 * d * acc;
+        // ---- waves 0..2: variable entries of F~^T ; last wave: v' = Vx + Vxx d and the gap terms
+        if (wave != kLast) {
+            M::expand_var(c, s + L::REC, s + L::FT, SI, tid, kThreadsMW - kWave);
+        } else if (lane < NX) {
+            double acc = 0.0;
+#pragma unroll 2
+            for (int m = 0; m < SV; m += 2) {
+                const double2_t v = lds2(s + L::VXX + lane * SV + m), d = lds2(s + L::DK + m);
+                acc += v.x * d.x + v.y * d.y;                                             // pads of DK and Vxx are zero
             }
-            G1 += wave_sum(g1);
-            G2 += wave_sum(g2);
+            const double d = s[L::DK + lane], vx = s[L::VX + lane];
+            s[L::VP + lane] = vx + acc;
+            g1_acc += d * vx;
+            g2_acc += 0.5 * d * acc;
         }
         __syncthreads();
         SDDP_TICK(2)
-        // ---- WT = (V~ F~)^T : one thread per element; dynamics rows by an NX-deep product, extra rows by a scaling
-        for (int e = tid; e < NZ * NX; e += kThreadsMW) {
-            const int j = e / NX, l = e % NX;
-            double acc = 0.0;
-#pragma unroll 4
-            for (int m = 0; m < NXP; m += 2) {
-                const double2_t v = lds2(s + L::VXX + l * NXP + m), f = lds2(s + L::FT + j * NIP + m);
-                acc += v.x * f.x + v.y * f.y;                    // Vxx pad column is zero: the FT word beyond NX is harmless
-            }
-            s[L::WT + j * NIP + l] = acc;
+        // ---- WT = (V~ F~)^T : JW x LW register blocks over the NX dynamics rows ; extra rows are a scaling of F~^T
+        for (int blk = tid; blk < L::NJB * L::NLB; blk += kThreadsMW) {
+            const int j0 = L::JW * (blk % L::NJB), l0 = L::LW * (blk / L::NJB);
+            double acc[L::JW][L::LW] = {};
+            dot_block<L::JW, L::LW>(s + L::FT + j0 * SI, SI, s + L::VXX + l0 * SV, SV, SV, acc);   // Vxx pad column is zero
+#pragma unroll
+            for (int jj = 0; jj < L::JW; ++jj)
+#pragma unroll
+                for (int ll = 0; ll < L::LW; ++ll)
+                    if (j0 + jj < NZ && l0 + ll < NX) s[L::WT + (j0 + jj) * SI + l0 + ll] = acc[jj][ll];
         }
         for (int e = tid; e < NZ * NE; e += kThreadsMW) {
             const int j = e / NE, m = e % NE;
             const double lam = state * s[L::LS + m] + s[L::LG + m];
-            s[L::WT + j * NIP + NX + m] = lam * s[L::FT + j * NIP + NX + m];
+            s[L::WT + j * SI + NX + m] = lam * s[L::FT + j * SI + NX + m];
         }
         __syncthreads();
         SDDP_TICK(3)
-        // ---- Q = diag(D) + F~^T (V~ F~): one thread per lower-triangle element, mirrored ; q = g + F^T v'
+        // ---- Q = diag(D) + F~^T (V~ F~): 3x3 lower-triangle blocks, mirrored ; q = g + F^T v'
         for (int t = tid; t < L::NTRIQ; t += kThreadsMW) {
-            const int code = ki[2 * NZP + t];
-            const int a = code >> 8, b = code & 255;
-            double acc = 0.0;
-#pragma unroll 4
-            for (int l = 0; l < NIP; l += 2) {
-                const double2_t f = lds2(s + L::FT + a * NIP + l), w = lds2(s + L::WT + b * NIP + l);
-                acc += f.x * w.x + f.y * w.y;
+            const int code = ki[2 * SQ + t];
+            const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
+            double acc[3][3] = {};
+            dot_block<3, 3>(s + L::FT + a0 * SI, SI, s + L::WT + b0 * SI, SI, SI, acc);
+            if (a0 == b0) {   // diagonal block: add D, keep it exactly symmetric
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (a0 + i < NZ)
+                        acc[i][i] += state * s[L::DS + a0 + i] + s[L::DG + a0 + i] +
+                                     M::dparam(c, s + L::PK, ki[a0 + i], ki[SQ + a0 + i], state, 1.0);
+#pragma unroll
+                    for (int j = 0; j < i; ++j) { const double off = 0.5 * (acc[i][j] + acc[j][i]); acc[i][j] = acc[j][i] = off; }
+                }
             }
-            if (a == b) acc += state * s[L::DS + a] + s[L::DG + a] + M::dparam(c, s + L::PK, ki[a], ki[NZP + a], state, 1.0);
-            s[L::Q + a * NZP + b] = acc;
-            s[L::Q + b * NZP + a] = acc;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (a0 + i < NZ && b0 + j < NZ) {
+                        s[L::Q + (a0 + i) * SQ + b0 + j] = acc[i][j];
+                        if (a0 != b0) s[L::Q + (b0 + j) * SQ + a0 + i] = acc[i][j];
+                    }
         }
-        if (wave == kLastWaveMW) {
+        if (wave == kLast) {
             for (int j = lane; j < NZ; j += kWave) {
                 double acc = s[L::REC + M::REC_G + j];
-                for (int m = 0; m < NX; ++m) acc += s[L::FT + j * NIP + m] * s[L::VP + m];
+#pragma unroll 2
+                for (int m = 0; m < SV; m += 2) {
+                    const double2_t f = lds2(s + L::FT + j * SI + m), v = lds2(s + L::VP + m);
+                    acc += f.x * ((m < NX) ? v.x : 0.0) + f.y * ((m + 1 < NX) ? v.y : 0.0);
+                }
                 s[L::QV + j] = acc;
             }
         }
         __syncthreads();
         if (theta != 0.0) {   // exact second-order torque term (uniform switch)
-            M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, NZP, theta, tid, kThreadsMW);
+            M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, SQ, theta, tid, kThreadsMW);
             __syncthreads();
         }
         SDDP_TICK(4)
-        // ---- [k K] = -Quu^-1 [Qu Qux]: Gauss-Jordan in wave 0, lane j owns column j of [Quu+mu I | Qu | Qux]
-        if (wave == 0) {
-            double a[NU];
+        // ---- [k K] = -Quu^-1 [Qu Qux]: block Gauss-Jordan, lane j = column j of [Quu+mu I | Qu | Qux], wave w = rows w RPW ..
+        {
+            double a[RPW], qu_save[RPW];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) {
+            for (int r = 0; r < RPW; ++r) {
+                const int i = wave * RPW + r;
                 double v = 0.0;
-                if (lane < NU) v = s[L::Q + (NX + i) * NZP + NX + lane] + (i == lane ? mu : 0.0);
-                else if (lane == NU) v = s[L::QV + NX + i];
-                else if (lane < NCOL) v = s[L::Q + (NX + i) * NZP + (lane - NU - 1)];
-                a[i] = v;
+                if (i < NU) {
+                    if (lane < NU) v = s[L::Q + (NX + i) * SQ + NX + lane] + (i == lane ? mu : 0.0);
+                    else if (lane == NU) v = s[L::QV + NX + i];
+                    else if (lane < NCOL) v = s[L::Q + (NX + i) * SQ + (lane - NU - 1)];
+                }
+                a[r] = v;
+                qu_save[r] = v;
+                qu_acc = fmax(qu_acc, fabs(v));          // only lane NU's value is used
             }
-            double qu_abs = 0.0, dv = 0.0, qu_save[NU];
+            for (int blk = 0; blk < kWavesMW; ++blk) {
+                double* gt = s + L::GT + (blk & 1) * RPW * kWave;
+                if (wave == blk) {
+                    bool ok = true;
 #pragma unroll
-            for (int i = 0; i < NU; ++i) { qu_save[i] = a[i]; qu_abs = fmax(qu_abs, fabs(a[i])); }
-            qu_inf = fmax(qu_inf, readlane_d(qu_abs, NU));
-            bool ok = true;
+                    for (int r = 0; r < RPW; ++r) {
+                        const int p = blk * RPW + r;
+                        if (p < NU) {
+                            double pv[RPW];
 #pragma unroll
-            for (int p = 0; p < NU; ++p) {
-                double pv[NU];
+                            for (int rr = 0; rr < RPW; ++rr) pv[rr] = readlane_d(a[rr], p);
+                            if (!(pv[r] > 0.0) || !(pv[r] < 1e300)) ok = false;
+                            const double t = a[r] * fast_rcp(pv[r]);
 #pragma unroll
-                for (int i = 0; i < NU; ++i) pv[i] = readlane_d(a[i], p);
-                if (!(pv[p] > 0.0) || !(pv[p] < 1e300)) ok = false;
-                const double t = a[p] * fast_rcp(pv[p]);
+                            for (int rr = 0; rr < RPW; ++rr) a[rr] = (rr == r) ? t : fma(-pv[rr], t, a[rr]);
+                        }
+                    }
 #pragma unroll
-                for (int i = 0; i < NU; ++i) a[i] = (i == p) ? t : fma(-pv[i], t, a[i]);
+                    for (int r = 0; r < RPW; ++r) gt[r * kWave + lane] = a[r];
+                    if (lane == 0) s[L::CTL + 14 + (blk & 1)] = ok ? 1.0 : 0.0;
+                }
+                __syncthreads();
+                if (s[L::CTL + 14 + (blk & 1)] == 0.0) return false;
+                if (wave != blk) {
+                    double pv[RPW][RPW];
+#pragma unroll
+                    for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) pv[rr][r] = readlane_d(a[rr], min(blk * RPW + r, NU - 1));
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+                        if (blk * RPW + r < NU) {
+                            const double t = gt[r * kWave + lane];
+#pragma unroll
+                            for (int rr = 0; rr < RPW; ++rr) a[rr] = fma(-pv[rr][r], t, a[rr]);
+                        }
+                    }
+                }
             }
-            if (lane == NU) {
+            // a = Quu^-1 * column ; publish kff and K^T (negated) ; dV1 += kff . Qu
+            double dv = 0.0;
 #pragma unroll
-                for (int i = 0; i < NU; ++i) s[L::KF + i] = -a[i];
+            for (int r = 0; r < RPW; ++r) {
+                const int i = wave * RPW + r;
+                if (i < NU) {
+                    if (lane == NU) s[L::KF + i] = -a[r];
+                    if (lane > NU && lane < NCOL) s[L::KT + (lane - NU - 1) * SK + i] = -a[r];
+                    dv += -a[r] * qu_save[r];
+                }
             }
-            if (lane > NU && lane < NCOL) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) s[L::KT + (lane - NU - 1) * NUP + i] = -a[i];
-            }
-#pragma unroll
-            for (int i = 0; i < NU; ++i) dv += -a[i] * qu_save[i];
-            dV1 += readlane_d(dv, NU);
-            if (lane == 0) s[L::CTL + 0] = ok ? 1.0 : 0.0;
+            dv_acc += dv;                                 // only lane NU's value is used
         }
         __syncthreads();
         SDDP_TICK(5)
-        if (s[L::CTL + 0] == 0.0) return false;
-        // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + 1/2 (Qux^T K + K^T Qux): one thread per lower-triangle element, mirrored
-        if (wave == kLastWaveMW && lane < NX) {
+        // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + 1/2 (Qux^T K + K^T Qux): 2x2 lower-triangle blocks, mirrored
+        if (wave == kLast && lane < NX) {
             double acc = s[L::QV + lane];
-            for (int i = 0; i < NU; ++i) acc += s[L::Q + lane * NZP + NX + i] * s[L::KF + i];
+            for (int i = 0; i < NU; ++i) acc += s[L::Q + lane * SQ + NX + i] * s[L::KF + i];
             s[L::VX + lane] = acc;
         }
         for (int t = tid; t < L::NTRIV; t += kThreadsMW) {
-            const int code = ki[2 * NZP + L::NTRIQ + t];
-            const int a = code >> 8, b = code & 255;
-            double acc = 0.0;
+            const int code = ki[2 * SQ + L::NTRIQ + t];
+            const int a0 = 2 * (code >> 8), c0 = 2 * (code & 255);
+            const int a1 = a0 + 1 < NX ? a0 + 1 : a0, c1 = c0 + 1 < NX ? c0 + 1 : c0;    // odd NX: clamp, not stored
+            double v00 = 0, v01 = 0, v10 = 0, v11 = 0;
 #pragma unroll 4
-            for (int i = 0; i < NU; ++i)
-                acc += s[L::Q + a * NZP + NX + i] * s[L::KT + b * NUP + i] + s[L::Q + b * NZP + NX + i] * s[L::KT + a * NUP + i];
-            acc = s[L::Q + a * NZP + b] + 0.5 * acc;
-            s[L::VXX + a * NXP + b] = acc;
-            s[L::VXX + b * NXP + a] = acc;
+            for (int i = 0; i < NU; ++i) {
+                const double qa = s[L::Q + a0 * SQ + NX + i], qb = s[L::Q + a1 * SQ + NX + i];
+                const double qc = s[L::Q + c0 * SQ + NX + i], qd = s[L::Q + c1 * SQ + NX + i];
+                const double ka = s[L::KT + a0 * SK + i], kb = s[L::KT + a1 * SK + i];
+                const double kc = s[L::KT + c0 * SK + i], kd = s[L::KT + c1 * SK + i];
+                v00 += qa * kc + qc * ka;
+                v01 += qa * kd + qd * ka;
+                v10 += qb * kc + qc * kb;
+                v11 += qb * kd + qd * kb;
+            }
+            v00 = s[L::Q + a0 * SQ + c0] + 0.5 * v00;
+            v01 = s[L::Q + a0 * SQ + c1] + 0.5 * v01;
+            v10 = s[L::Q + a1 * SQ + c0] + 0.5 * v10;
+            v11 = s[L::Q + a1 * SQ + c1] + 0.5 * v11;
+            if (a0 == c0) { const double off = 0.5 * (v01 + v10); v01 = v10 = off; }
+            const bool ha = a0 + 1 < NX, hc = c0 + 1 < NX;
+            s[L::VXX + a0 * SV + c0] = v00;
+            if (hc) s[L::VXX + a0 * SV + c0 + 1] = v01;
+            if (ha) s[L::VXX + (a0 + 1) * SV + c0] = v10;
+            if (ha && hc) s[L::VXX + (a0 + 1) * SV + c0 + 1] = v11;
+            if (a0 != c0) {
+                s[L::VXX + c0 * SV + a0] = v00;
+                if (hc) s[L::VXX + (c0 + 1) * SV + a0] = v01;
+                if (ha) s[L::VXX + c0 * SV + a0 + 1] = v10;
+                if (ha && hc) s[L::VXX + (c0 + 1) * SV + a0 + 1] = v11;
+            }
         }
         // ---- gains to HBM/L2: kff (NU) then K (NU x NX) row-major, coalesced
         {
@@ -260,62 +371,129 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             for (int e = tid; e < NU * (NX + 1); e += kThreadsMW) {
                 double v;
                 if (e < NU) v = s[L::KF + e];
-                else { const int i = (e - NU) / NX, j = (e - NU) % NX; v = s[L::KT + j * NUP + i]; }
+                else { const int i = (e - NU) / NX, j = (e - NU) % NX; v = s[L::KT + j * SK + i]; }
                 gk[e] = v;
             }
         }
         __syncthreads();
         SDDP_TICK(6)
     }
+    // ---- combine the per-wave partial sums (same values, same order in every thread)
+    if (wave == kLast) {
+        g1_acc = wave_sum(g1_acc);
+        g2_acc = wave_sum(g2_acc);
+        if (lane == 0) { s[L::CTL + 1] = g1_acc; s[L::CTL + 2] = g2_acc; }
+    }
+    if (lane == NU) { s[L::CTL + 4 + wave] = dv_acc; s[L::CTL + 8 + wave] = qu_acc; }
+    __syncthreads();
+    G1 = s[L::CTL + 1];
+    G2 = s[L::CTL + 2];
+#pragma unroll
+    for (int w = 0; w < kWavesMW; ++w) { dV1 += s[L::CTL + 4 + w]; qu_inf = fmax(qu_inf, s[L::CTL + 8 + w]); }
+    __syncthreads();
     return true;
 }
 
-// forward pass on ONE wave, no workgroup barrier inside (the other waves wait at the next barrier meanwhile): per-lane
-// vectors in LDS columns for the wide models, in registers with direct (wave-uniform) operand loads otherwise
+// forward pass on 4 waves (called by every thread): lane l of every wave works on step length alpha_l.
+// Returns the cost of lane l's trajectory in wave 0 (other waves: unspecified).  Clobbers the WT and Q tiles.
 template <class M, bool OPEN_LOOP>
-__device__ double rollout_w(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
-                            const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
-                            const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
-                            double alpha, int store_lane, int lane, double* s SDDP_T_ARG) {
-    if constexpr (LdsMW<M>::WIDE) {
-        return rollout_lds_core<M, OPEN_LOOP>(c, N, x0, P, xs, us, dft, gains, xn, un, alpha, store_lane, lane, s + LdsMW<M>::WT SDDP_T_PASS);
-    } else {
-        constexpr int NX = M::NX, NU = M::NU;
-        double x[NX];
-        for (int i = 0; i < NX; ++i) x[i] = x0[i];
-        double J = 0.0;
-        const double oma = 1.0 - alpha;
-        for (int k = 0; k < N; ++k) {
-            double u[NU], xnext[NX];
-            if (OPEN_LOOP) {
-                for (int i = 0; i < NU; ++i) u[i] = us[k * NU + i];
-            } else {
-                double dx[NX];
-                for (int j = 0; j < NX; ++j) dx[j] = x[j] - xs[k * NX + j];
-                const double* gk = gains + size_t(k) * (NU * (NX + 1));
-                for (int i = 0; i < NU; ++i) {
-                    double acc = us[k * NU + i] + alpha * gk[i];
-                    for (int j = 0; j < NX; ++j) acc += gk[NU + i * NX + j] * dx[j];
-                    u[i] = acc;
+__device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
+                             const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
+                             const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
+                             double alpha, int store_lane, int tid, double* s SDDP_T_ARG) {
+    using L = LdsMW<M>;
+    constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = NU * (NX + 1), SG = L::SG;
+    constexpr int UPW = (NU + kWavesMW - 1) / kWavesMW;            // feedback rows per wave
+    constexpr int kStagers = kThreadsMW - kWave;
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    const LdsCol X{s + L::RO_X + lane}, Y{s + L::RO_Y + lane}, U{s + L::RO_U + lane};
+    double* kf = s + L::RO_G;                                      // staged gains of one knot: kff [NU]
+    double* kb = s + L::RO_K;                                      //                           K [NU][SG]
+    auto stage_gains = [&](int k) {                                // waves 1..3: one knot's gains, coalesced, into LDS
+        const double* gk = gains + size_t(k) * NG;
+        for (int e = tid - kWave; e < NG; e += kStagers) {
+            const double v = gk[e];
+            if (e < NU) kf[e] = v;
+            else { const int i = (e - NU) / NX, j = (e - NU) % NX; kb[i * SG + j] = v; }
+        }
+    };
+    __syncthreads();                                               // the tiles this pass aliases are no longer read
+    if (wave == 0) {
+        for (int i = 0; i < NX; ++i) Y[i] = x0[i];
+    } else if (!OPEN_LOOP) {
+        stage_gains(0);
+    }
+    double J = 0.0;
+    const double oma = 1.0 - alpha;
+    for (int k = 0; k < N; ++k) {
+        SDDP_TICK(8)
+        // ---- A: wave 0 closes the previous knot: x_k = f(x_{k-1}, u_{k-1}) - (1 - alpha) d_{k-1}
+        if (wave == 0) {
+            if (k == 0 || OPEN_LOOP) { for (int i = 0; i < NX; ++i) X[i] = Y[i]; }
+            else { for (int i = 0; i < NX; ++i) X[i] = Y[i] - oma * dft[(k - 1) * NX + i]; }
+        }
+        __syncthreads();
+        // ---- B: every wave computes UPW rows of u = u_k + alpha kff + K (x - x_k)
+        {
+            double dx[NX];
+            if (!OPEN_LOOP) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) dx[j] = X[j];
+                if (wave == kWavesMW - 1 && lane == store_lane) {
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) xn[k * NX + j] = dx[j];
+                }
+#pragma unroll
+                for (int j = 0; j < NX; ++j) dx[j] -= xs[k * NX + j];
+            } else if (wave == kWavesMW - 1 && lane == store_lane) {
+                for (int j = 0; j < NX; ++j) xn[k * NX + j] = X[j];
+            }
+#pragma unroll
+            for (int r = 0; r < UPW; ++r) {
+                const int i = wave * UPW + r;
+                if (i < NU) {
+                    double acc = us[k * NU + i];
+                    if (!OPEN_LOOP) {
+                        acc += alpha * kf[i];
+                        const double* row = kb + i * SG;
+#pragma unroll
+                        for (int j = 0; j + 1 < NX; j += 2) {
+                            const double2_t g = lds2(row + j);
+                            acc = fma(g.y, dx[j + 1], fma(g.x, dx[j], acc));
+                        }
+                        if (NX & 1) acc = fma(row[NX - 1], dx[NX - 1], acc);
+                    }
+                    U[i] = acc;
+                    if (lane == store_lane) un[k * NU + i] = acc;
                 }
             }
-            J += M::step(c, x, u, P + k * M::NP, k, xnext);
-            if (lane == store_lane) {
-                for (int i = 0; i < NX; ++i) xn[k * NX + i] = x[i];
-                for (int i = 0; i < NU; ++i) un[k * NU + i] = u[i];
-            }
-            for (int i = 0; i < NX; ++i) x[i] = OPEN_LOOP ? xnext[i] : xnext[i] - oma * dft[k * NX + i];
         }
-        J += M::term_cost(c, x, P + N * M::NP);
-        if (lane == store_lane) {
-            for (int i = 0; i < NX; ++i) xn[N * NX + i] = x[i];
-        }
-        return J;
+        __syncthreads();
+        SDDP_TICK(10)
+        // ---- C: wave 0 steps the model; the other waves stage the next knot's gains
+        if (wave == 0) J += M::step(c, X, U, P + k * NP, k, Y);
+        else if (!OPEN_LOOP && k + 1 < N) stage_gains(k + 1);
+        SDDP_TICK(12)
     }
+    if (wave == 0) {
+        if (OPEN_LOOP) { for (int i = 0; i < NX; ++i) X[i] = Y[i]; }
+        else { for (int i = 0; i < NX; ++i) X[i] = Y[i] - oma * dft[(N - 1) * NX + i]; }
+        J += M::term_cost(c, X, P + N * NP);
+        if (lane == store_lane) {
+            for (int i = 0; i < NX; ++i) xn[N * NX + i] = X[i];
+        }
+    }
+    return J;
 }
 
-// fused persistent solve, 4 waves per instance.  Control words: CTL[1] = code (0 step accepted, 1 accepted and stop,
-// 2 stop without a step, 3 redo the iteration with theta = 0, 4 non-finite start), CTL[2] = accepted alpha.
+// re-zero what the forward pass clobbered and the sweep relies on: the WT tile (its pad columns / rows are summed over)
+template <class M>
+__device__ __forceinline__ void restore_tiles_mw(double* s, int tid) {
+    using L = LdsMW<M>;
+    for (int e = tid; e < L::RZ * L::SI; e += kThreadsMW) s[L::WT + e] = 0.0;
+}
+
+// fused persistent solve, 4 waves per instance
 template <class M>
 __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double s[];
@@ -338,8 +516,9 @@ __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
     double J = 0.0, gap = 0.0;
     SDDP_T_DECL
     sweep_tables_mw<M>(A.c, s, tid);
+    // ---- starting point (cost and defect norm computed by wave 0, shared through CTL)
     if (o.initial_rollout) {
-        if (wave == 0) J = rollout_w<M, true>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, lane, s SDDP_T_PASS);
+        J = rollout_mw<M, true>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, tid, s SDDP_T_PASS);
         __syncthreads();
         for (int e = tid; e < (N + 1) * NX; e += kThreadsMW) xs[e] = xn[e];
         for (int e = tid; e < N * NX; e += kThreadsMW) dft[e] = 0.0;
@@ -348,95 +527,99 @@ __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
         __syncthreads();
         if (wave == 0) phase_defects<M>(A.c, N, xs, us, P, dft, lane, J, gap);
     }
-    if (tid == 0) s[L::CTL + 1] = (fabs(J) < 1e300) ? 0.0 : 4.0;
+    if (tid == 0) { s[L::CTL + 12] = J; s[L::CTL + 13] = gap; }
+    __syncthreads();
+    J = s[L::CTL + 12];
+    gap = s[L::CTL + 13];
     __syncthreads();
     double mu = o.mu0, rho = 0.0, alpha = 0.0, expected = 0.0, theta = 0.0;
     int iters = 0, converged = 0, status = 1, rollouts = 0, guess = 0;
-    if (s[L::CTL + 1] == 4.0) status = 3;
+    if (!(fabs(J) < 1e300)) { status = 3; }
     else
         while (iters < o.max_iters) {
             SDDP_TICK(9)
             if (wave == 0) phase_derivs<M>(A.c, N, xs, us, P, rec, lane);
-            SDDP_TICK(0)
-            if (L::WIDE)   // the wide rollout's columns lived in the WT / Q tiles: restore the zero pads of WT
-                for (int e = tid; e < L::NZP * L::NIP; e += kThreadsMW) s[L::WT + e] = 0.0;
+            restore_tiles_mw<M>(s, tid);
             __syncthreads();
-            double dV1, G1, G2, qu_inf;
-            bool ok;
-            while (true) {
-                ok = backward_sweep_mw<M>(A.c, N, P, dft, rec, gains, mu, theta, s, tid, dV1, G1, G2, qu_inf SDDP_T_PASS);
-                if (ok) break;
-                if (theta != 0.0) { theta = 0.0; continue; }      // identical in every wave
-                mu = fmax(mu, 0.0) * 10.0 + o.mu_min;
-                if (mu > o.mu_max) break;
-            }
-            if (!ok) { status = 2; break; }
-            if (wave == 0) {   // convergence test, merit weight, line search
-                double code = 0.0;
+            SDDP_TICK(0)
+            double dV1, G1, G2, qu_inf, a_win = 0.0, J_win = 0.0;
+            bool ok = true, stop = false, accepted = false;
+            do {   // at most twice: a failed sweep / line search with the second-order term is redone without it
+                while (true) {
+                    ok = backward_sweep_mw<M>(A.c, N, P, dft, rec, gains, mu, theta, s, tid, dV1, G1, G2, qu_inf SDDP_T_PASS);
+                    if (ok) break;
+                    if (theta != 0.0) { theta = 0.0; continue; }
+                    mu = fmax(mu, 0.0) * 10.0 + o.mu_min;
+                    if (mu > o.mu_max) break;
+                }
+                if (!ok) { status = 2; stop = true; break; }
                 const double dV2 = -0.5 * dV1;
                 expected = -(dV1 + dV2);
-                if (expected < o.cost_reduction_ths && gap <= o.gap_tol) { converged = 1; status = 0; code = 2.0; }
-                else {
-                    const double A1 = dV1 + G1, B2 = dV2 + G2;
-                    if (gap > 0.0) rho = fmax(rho, 2.0 * fmax(fmax(A1, A1 + B2), 0.0) / gap);
-                    const double slack = 1e-13 * (fabs(J) + rho * gap);
-                    bool accepted = false;
-                    double a_base = o.alpha_0, a_win = 0.0, J_win = 0.0;
-                    while (a_base >= o.alpha_converge_threshold) {
-                        double a = a_base;
-                        for (int j = 0; j < lane; ++j) a *= o.line_search_decrease_factor;
-                        const bool valid = a >= o.alpha_converge_threshold;
-                        SDDP_TICK(9)
-                        const double Jl = rollout_w<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, guess, lane, s SDDP_T_PASS);
-                        SDDP_TICK(8)
-                        ++rollouts;
+                if (expected < o.cost_reduction_ths && gap <= o.gap_tol) { converged = 1; status = 0; stop = true; break; }
+                const double A1 = dV1 + G1, B2 = dV2 + G2;
+                if (gap > 0.0) rho = fmax(rho, 2.0 * fmax(fmax(A1, A1 + B2), 0.0) / gap);
+                const double slack = 1e-13 * (fabs(J) + rho * gap);
+                // ---- line search: lane j tries alpha_0 * factor^j (the ladder of ddp.py:20-28 in one pass)
+                accepted = false;
+                bool tiles_dirty = false;
+                double a_base = o.alpha_0;
+                while (a_base >= o.alpha_converge_threshold) {
+                    double a = a_base;
+                    for (int j = 0; j < lane; ++j) a *= o.line_search_decrease_factor;
+                    const bool valid = a >= o.alpha_converge_threshold;
+                    SDDP_TICK(9)
+                    const double Jl = rollout_mw<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, guess, tid, s SDDP_T_PASS);
+                    SDDP_TICK(8)
+                    tiles_dirty = true;
+                    ++rollouts;
+                    if (wave == 0) {
                         const double pred = a * A1 + a * a * B2 - a * rho * gap;
                         const double dphi = (Jl + rho * (1.0 - a) * gap) - (J + rho * gap);
                         const bool good = valid && (fabs(Jl) < 1e300) && (dphi <= o.beta * pred + slack);
                         const unsigned long long mask = __ballot(good);
-                        if (mask) {
-                            const int win = __ffsll((long long)mask) - 1;
-                            a_win = __shfl(a, win, kWave);
-                            J_win = __shfl(Jl, win, kWave);
-                            if (win != guess) {
-                                rollout_w<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, lane, s SDDP_T_PASS);
-                                ++rollouts;
-                            }
-                            guess = win;
-                            accepted = true;
-                            break;
+                        const int win = mask ? __ffsll((long long)mask) - 1 : -1;
+                        const double jw = __shfl(Jl, win < 0 ? 0 : win, kWave);
+                        if (lane == 0) { s[L::CTL + 12] = double(win); s[L::CTL + 13] = jw; }
+                    }
+                    __syncthreads();
+                    const int win = int(s[L::CTL + 12]);
+                    if (win >= 0) {
+                        a_win = __shfl(a, win, kWave);
+                        J_win = s[L::CTL + 13];
+                        if (win != guess) {   // the accepted lane's trajectory was not the one stored: roll it again
+                            rollout_mw<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, tid, s SDDP_T_PASS);
+                            ++rollouts;
                         }
-                        a_base = __shfl(a, kWave - 1, kWave) * o.line_search_decrease_factor;
-                        guess = 0;
+                        guess = win;
+                        accepted = true;
+                        break;
                     }
-                    if (!accepted) {
-                        if (theta != 0.0) code = 3.0;                                          // redo with plain Gauss-Newton
-                        else { alpha = 0.0; converged = 1; status = 0; code = 2.0; }           // alpha below the threshold
-                    } else {
-                        alpha = a_win;
-                        const double dJ = J - J_win;
-                        J = J_win;
-                        gap *= (1.0 - alpha);
-                        ++iters;
-                        if (fabs(dJ) < o.cost_reduction_ths && gap <= o.gap_tol) { converged = 1; status = 0; code = 1.0; }
-                    }
+                    a_base = __shfl(a, kWave - 1, kWave) * o.line_search_decrease_factor;
+                    guess = 0;
                 }
-                if (lane == 0) { s[L::CTL + 1] = code; s[L::CTL + 2] = alpha; }
-            }
-            __syncthreads();
-            const double code = s[L::CTL + 1];
-            if (code == 2.0) break;
-            if (code == 3.0) { theta = 0.0; __syncthreads(); continue; }
-            const double a_acc = s[L::CTL + 2];
+                if (!accepted && theta != 0.0) {   // fall back to the plain Gauss-Newton sweep once
+                    theta = 0.0;
+                    if (tiles_dirty) { __syncthreads(); restore_tiles_mw<M>(s, tid); __syncthreads(); }
+                    continue;
+                }
+                break;
+            } while (true);
+            if (stop) break;
+            if (!accepted) { alpha = 0.0; converged = 1; status = 0; break; }   // alpha below the threshold: no progress possible
+            alpha = a_win;
+            const double dJ = J - J_win;
+            J = J_win;
             { double* t = xs; xs = xn; xn = t; }
             { double* t = us; us = un; un = t; }
-            const double oma = 1.0 - a_acc;
+            const double oma = 1.0 - alpha;
+            __syncthreads();
             for (int e = tid; e < N * NX; e += kThreadsMW) dft[e] *= oma;
-            if (wave != 0) ++iters;
-            theta = (o.second_order && a_acc == o.alpha_0) ? 1.0 : 0.0;
+            gap *= oma;
+            ++iters;
+            theta = (o.second_order && alpha == o.alpha_0) ? 1.0 : 0.0;
             if (mu > o.mu0) mu = fmax(o.mu0, mu * 0.1);
             __syncthreads();
-            if (code == 1.0) break;
+            if (fabs(dJ) < o.cost_reduction_ths && gap <= o.gap_tol) { converged = 1; status = 0; break; }
         }
     __syncthreads();
     double* xs0 = A.xs + size_t(b) * (N + 1) * NX;
@@ -471,6 +654,7 @@ __global__ __launch_bounds__(kThreadsMW) void backward_kernel_mw(SolveArgs A) {
     double* gains = A.gains + size_t(b) * N * (NU * (NX + 1));
     double* rec = A.rec + size_t(b) * (N + 1) * NREC;
     double J = 0.0, gap = 0.0;
+    SDDP_T_DECL
     sweep_tables_mw<M>(A.c, s, tid);
     if (wave == 0) {
         phase_defects<M>(A.c, N, xs, us, P, dft, lane, J, gap);
@@ -478,12 +662,26 @@ __global__ __launch_bounds__(kThreadsMW) void backward_kernel_mw(SolveArgs A) {
     }
     __syncthreads();
     double dV1, G1, G2, qu_inf;
-    SDDP_T_DECL
     const bool ok = backward_sweep_mw<M>(A.c, N, P, dft, rec, gains, A.mu, A.alpha, s, tid, dV1, G1, G2, qu_inf SDDP_T_PASS);
     if (tid == 0) {
         double* sc = A.scal + size_t(b) * kScal;
         sc[0] = dV1; sc[1] = -0.5 * dV1; sc[2] = G1; sc[3] = G2; sc[4] = ok ? 1.0 : 0.0; sc[5] = A.mu; sc[6] = qu_inf; sc[7] = J;
     }
+}
+
+template <class M>
+__global__ __launch_bounds__(kThreadsMW) void forward_kernel_mw(SolveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double s[];
+    constexpr int NX = M::NX, NU = M::NU, NP = M::NP;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= A.B) return;
+    const int N = A.N;
+    SDDP_T_DECL
+    const double J = rollout_mw<M, false>(A.c, N, A.x0 + size_t(b) * NX, A.P + size_t(b) * (N + 1) * NP,
+                                          A.xs + size_t(b) * (N + 1) * NX, A.us + size_t(b) * N * NU,
+                                          A.dft + size_t(b) * N * NX, A.gains + size_t(b) * N * (NU * (NX + 1)),
+                                          A.xn + size_t(b) * (N + 1) * NX, A.un + size_t(b) * N * NU, A.alpha, 0, tid, s SDDP_T_PASS);
+    if (tid == 0) A.scal[size_t(b) * kScal] = J;
 }
 
 }  // namespace sddp

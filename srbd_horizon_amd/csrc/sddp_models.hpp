@@ -755,7 +755,8 @@ struct LipModel {
     __device__ __forceinline__ static double p_cref(const double* p, int i) { return p[3 + 2 * i]; }
     __device__ __forceinline__ static double p_sw(const double* p, int i) { return p[4 + 2 * i]; }
 
-    __device__ __forceinline__ static double state_cost(const DevConsts& c, const double* x, const double* p) {
+    template <class XV>
+    __device__ __forceinline__ static double state_cost(const DevConsts& c, XV x, const double* p) {
         const double ez = x[2] - c.com_z;
         double L = c.w_rz * ez * ez;                                              // rz_tracking  prb.py:390
 #pragma unroll
@@ -772,8 +773,8 @@ struct LipModel {
         return L;
     }
 
-    __device__ __forceinline__ static double step(const DevConsts& c, const double* x, const double* u, const double* p,
-                                                  int k, double* xn) {
+    template <class XV, class UV, class XN>
+    __device__ __forceinline__ static double step(const DevConsts& c, XV x, UV u, const double* p, int k, XN xn) {
         double L = 0, rddot[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -806,7 +807,8 @@ struct LipModel {
         return L;
     }
 
-    __device__ __forceinline__ static double term_cost(const DevConsts& c, const double* x, const double* p) {
+    template <class XV>
+    __device__ __forceinline__ static double term_cost(const DevConsts& c, XV x, const double* p) {
         return state_cost(c, x, p);
     }
 
