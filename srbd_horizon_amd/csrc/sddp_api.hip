@@ -87,7 +87,13 @@ SolveArgs make_args(sddp_handle* h, const double* d_params) {
 
 // large models (> 48 KB of LDS per instance: srbd37, lip30) run on 4 waves per instance (sddp_kernels_mw.hpp)
 template <class M>
-constexpr bool use_mw() { return Lds<M>::BYTES > 48 * 1024; }
+constexpr bool use_mw() {
+#ifdef SDDP_MW_ALL
+    return true;
+#else
+    return Lds<M>::BYTES > 48 * 1024;
+#endif
+}
 
 template <class M>
 int launch_solve(sddp_handle* h, const SolveArgs& a) {

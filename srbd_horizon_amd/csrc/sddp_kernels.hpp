@@ -284,21 +284,18 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         const double state = k >= 1 ? 1.0 : 0.0;
         // ---- expand: variable entries of F~^T; v' = Vx + Vxx d ; gap terms
         M::expand_var(c, s + L::REC, s + L::FT, NIP, lane);
-        double g1 = 0.0, g2 = 0.0;
         if (lane < NX) {
             double acc = 0.0;
 #pragma unroll
             for (int m = 0; m < NXP; m += 2) {
                 const double2_t v = lds2(s + L::VXX + lane * NXP + m), d = lds2(s + L::DK + m);
-                acc += v.x * d.x + v.y * d.y;
+                acc = fma(v.y, d.y, fma(v.x, d.x, acc));
             }
             const double d = s[L::DK + lane], vx = s[L::VX + lane];
             s[L::VP + lane] = vx + acc;
-            g1 = d * vx;
-            g2 = 0.5 * d * acc;
+            G1 = fma(d, vx, G1);                 // per-lane partial sums, reduced once after the sweep
+            G2 = fma(0.5 * d, acc, G2);
         }
-        G1 += wave_sum(g1);
-        G2 += wave_sum(g2);
         __syncthreads();
         SDDP_TICK(2)
         // ---- WT = (V~ F~)^T : 2 (l) x 4 (j) register blocks, inner product over the NX dynamics rows
@@ -311,8 +308,8 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const double2_t f = lds2(s + L::FT + (j0 + jj) * NIP + m);
-                    a0[jj] += v0.x * f.x + v0.y * f.y;
-                    a1[jj] += v1.x * f.x + v1.y * f.y;
+                    a0[jj] = fma(v0.y, f.y, fma(v0.x, f.x, a0[jj]));
+                    a1[jj] = fma(v1.y, f.y, fma(v1.x, f.x, a1[jj]));
                 }
             }
 #pragma unroll
@@ -341,10 +338,10 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             for (int l = 0; l < NIP; l += 2) {
                 const double2_t fa = lds2(s + L::FT + a0 * NIP + l), fb = lds2(s + L::FT + (a0 + 1) * NIP + l);
                 const double2_t wa = lds2(s + L::WT + c0 * NIP + l), wb = lds2(s + L::WT + (c0 + 1) * NIP + l);
-                q00 += fa.x * wa.x + fa.y * wa.y;
-                q01 += fa.x * wb.x + fa.y * wb.y;
-                q10 += fb.x * wa.x + fb.y * wa.y;
-                q11 += fb.x * wb.x + fb.y * wb.y;
+                q00 = fma(fa.y, wa.y, fma(fa.x, wa.x, q00));
+                q01 = fma(fa.y, wb.y, fma(fa.x, wb.x, q01));
+                q10 = fma(fb.y, wa.y, fma(fb.x, wa.x, q10));
+                q11 = fma(fb.y, wb.y, fma(fb.x, wb.x, q11));
             }
             if (a0 == c0) {   // diagonal block: add D, keep it exactly symmetric
                 const double d0 = state * s[L::DS + a0] + s[L::DG + a0] + M::dparam(c, s + L::PK, ki[a0], ki[NZP + a0], state, 1.0);
@@ -370,7 +367,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
 #pragma unroll
             for (int m = 0; m < NXP; m += 2) {
                 const double2_t f = lds2(s + L::FT + j * NIP + m), v = lds2(s + L::VP + m);
-                acc += f.x * ((m < NX) ? v.x : 0.0) + f.y * ((m + 1 < NX) ? v.y : 0.0);
+                acc = fma(f.y, (m + 1 < NX) ? v.y : 0.0, fma(f.x, (m < NX) ? v.x : 0.0, acc));
             }
             s[L::QV + j] = acc;
         }
@@ -446,10 +443,10 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
                 const double qc = s[L::Q + c0 * NZP + NX + i], qd = s[L::Q + (c0 + 1) * NZP + NX + i];
                 const double ka = s[L::KT + a0 * NUP + i], kb = s[L::KT + (a0 + 1) * NUP + i];
                 const double kc = s[L::KT + c0 * NUP + i], kd = s[L::KT + (c0 + 1) * NUP + i];
-                v00 += qa * kc + qc * ka;
-                v01 += qa * kd + qd * ka;
-                v10 += qb * kc + qc * kb;
-                v11 += qb * kd + qd * kb;
+                v00 = fma(qc, ka, fma(qa, kc, v00));
+                v01 = fma(qd, ka, fma(qa, kd, v01));
+                v10 = fma(qc, kb, fma(qb, kc, v10));
+                v11 = fma(qd, kb, fma(qb, kd, v11));
             }
             v00 = s[L::Q + a0 * NZP + c0] + 0.5 * v00;
             v01 = s[L::Q + a0 * NZP + c0 + 1] + 0.5 * v01;
@@ -480,6 +477,8 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         __syncthreads();
         SDDP_TICK(6)
     }
+    G1 = wave_sum(G1);
+    G2 = wave_sum(G2);
     return ok;
 }
 

@@ -187,7 +187,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
 #pragma unroll 2
             for (int m = 0; m < SV; m += 2) {
                 const double2_t v = lds2(s + L::VXX + lane * SV + m), d = lds2(s + L::DK + m);
-                acc += v.x * d.x + v.y * d.y;                                             // pads of DK and Vxx are zero
+                acc = fma(v.y, d.y, fma(v.x, d.x, acc));                                  // pads of DK and Vxx are zero
             }
             const double d = s[L::DK + lane], vx = s[L::VX + lane];
             s[L::VP + lane] = vx + acc;
@@ -245,7 +245,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
 #pragma unroll 2
                 for (int m = 0; m < SV; m += 2) {
                     const double2_t f = lds2(s + L::FT + j * SI + m), v = lds2(s + L::VP + m);
-                    acc += f.x * ((m < NX) ? v.x : 0.0) + f.y * ((m + 1 < NX) ? v.y : 0.0);
+                    acc = fma(f.y, (m + 1 < NX) ? v.y : 0.0, fma(f.x, (m < NX) ? v.x : 0.0, acc));
                 }
                 s[L::QV + j] = acc;
             }
@@ -343,10 +343,10 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 const double qc = s[L::Q + c0 * SQ + NX + i], qd = s[L::Q + c1 * SQ + NX + i];
                 const double ka = s[L::KT + a0 * SK + i], kb = s[L::KT + a1 * SK + i];
                 const double kc = s[L::KT + c0 * SK + i], kd = s[L::KT + c1 * SK + i];
-                v00 += qa * kc + qc * ka;
-                v01 += qa * kd + qd * ka;
-                v10 += qb * kc + qc * kb;
-                v11 += qb * kd + qd * kb;
+                v00 = fma(qc, ka, fma(qa, kc, v00));
+                v01 = fma(qd, ka, fma(qa, kd, v01));
+                v10 = fma(qc, kb, fma(qb, kc, v10));
+                v11 = fma(qd, kb, fma(qb, kd, v11));
             }
             v00 = s[L::Q + a0 * SQ + c0] + 0.5 * v00;
             v01 = s[L::Q + a0 * SQ + c1] + 0.5 * v01;
