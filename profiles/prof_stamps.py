@@ -16,8 +16,8 @@ fn = eng.lib.sddp_debug_read_scal; fn.restype = C.c_int; fn.argtypes = [C.c_void
 assert fn(eng.h, sc.ctypes.data_as(C.c_void_p)) == 0
 it = eng.stats["iters"]; ro = eng.stats["rollouts"]
 names = ["derivs", "bw.stage", "bw.expand+vp", "bw.W=VxxF", "bw.Q=H+FtW", "bw.solve", "bw.Vupd+gains", "-", "rollout", "other"]
-names += ["ro.Kdx", "ro.store", "ro.step"]
-tot = sc[:, :13].sum(axis=1)
+names += ["ro.feedback", "ro.close-knot", "ro.step", "bw.Q.blocks(mw)", "bw.Q.qv+barrier(mw)"]
+tot = sc[:, :15].sum(axis=1)
 print("kernel ms", eng.last_kernel_ms(), "mean iters", it.mean(), "mean rollouts", ro.mean())
 print("cycles/iter (mean over instances): %.0f" % (tot / np.maximum(it, 1)).mean())
 for i, n in enumerate(names):

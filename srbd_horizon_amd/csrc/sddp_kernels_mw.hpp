@@ -69,27 +69,50 @@ struct LdsMW {
     // forward pass: per-lane vector columns X | Y | U and the staged gains of one knot alias WT and Q (and may run past Q)
     static constexpr int RO_X = WT, RO_Y = RO_X + NX * kWave, RO_U = RO_Y + NX * kWave, RO_G = RO_U + NU * kWave;
     static constexpr int RO_K = RO_G + ((NU + 1) & ~1);                        // kff [NU] | K [NU][SG]
-    static constexpr int RO_END = RO_K + NU * SG;
+    // knot operands staged beside the gains, double buffered: x_k [SG] | u_k [NUE] | d_k [SG] | p_k [NPE]
+    static constexpr int NUE = (NU + 1) & ~1, NPE = (M::NP + 1) & ~1;
+    static constexpr int SB_X = 0, SB_U = SG, SB_D = SB_U + NUE, SB_P = SB_D + SG, SB_N = SB_P + NPE;
+    static constexpr int RO_S = RO_K + NU * SG;
+    static constexpr int RO_END = RO_S + 2 * SB_N;
     static constexpr int TOTAL = imax(Q + RQ * SQ, RO_END);
     static constexpr size_t BYTES = size_t(TOTAL) * sizeof(double);
     static_assert((FT | VX | VP | QV | REC | PK | DK | KT | KF | GT | DS | DG | LS | LG | CTL | KI | WT | Q | RO_G) % 2 == 0, "16-byte aligned sections");
 };
 
-// C[i][j] += sum_m A[i][m] B[j][m], m < 2 * K2: RA x RB register block, rows read two fp64 at a time
-template <int RA, int RB>
-__device__ __forceinline__ void dot_block(const double* A, int lda, const double* B, int ldb, int depth, double (&acc)[RA][RB]) {
-#pragma unroll 2
-    for (int m = 0; m < depth; m += 2) {
-        double2_t a[RA], b[RB];
+// C[i][j] += sum_m A[i][m] B[j][m], m < DEPTH (even): RA x RB register block, rows read two fp64 at a time (ds_read_b128).
+// Software pipelined: the operands of pair q + PF are requested before the FMAs of pair q, so that with one wave per SIMD the
+// LDS round trip overlaps the arithmetic.  Ring of PF + 1 register buffers with static indices: the steady-state loop runs
+// over whole groups of PF + 1 pairs, the remainder is peeled.  The last groups request up to PF pairs past the end of the
+// rows (in bounds: every tile is followed by another LDS section); those values are never used.
+template <int RA, int RB, int DEPTH, int PF = 2>
+__device__ __forceinline__ void dot_block(const double* A, int lda, const double* B, int ldb, double (&acc)[RA][RB]) {
+    constexpr int NPAIR = DEPTH / 2, NB = PF + 1, NGRP = NPAIR / NB, REM = NPAIR % NB;
+    static_assert(DEPTH % 2 == 0 && NPAIR >= PF, "even depth, at least PF pairs");
+    double2_t a[NB][RA], b[NB][RB];
+    auto load = [&](int buf, int pair) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) a[i] = lds2(A + i * lda + m);
+        for (int i = 0; i < RA; ++i) a[buf][i] = lds2(A + i * lda + 2 * pair);
 #pragma unroll
-        for (int j = 0; j < RB; ++j) b[j] = lds2(B + j * ldb + m);
+        for (int j = 0; j < RB; ++j) b[buf][j] = lds2(B + j * ldb + 2 * pair);
+    };
+    auto mac = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
 #pragma unroll
-            for (int j = 0; j < RB; ++j) acc[i][j] = fma(a[i].y, b[j].y, fma(a[i].x, b[j].x, acc[i][j]));
+            for (int j = 0; j < RB; ++j) acc[i][j] = fma(a[buf][i].y, b[buf][j].y, fma(a[buf][i].x, b[buf][j].x, acc[i][j]));
+    };
+#pragma unroll
+    for (int q = 0; q < PF; ++q) load(q, q);
+#pragma unroll 1
+    for (int g = 0; g < NGRP; ++g) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            load((u + PF) % NB, g * NB + u + PF);
+            mac(u);
+        }
     }
+#pragma unroll
+    for (int u = 0; u < REM; ++u) mac(u);
 }
 
 template <class M>
@@ -200,7 +223,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         for (int blk = tid; blk < L::NJB * L::NLB; blk += kThreadsMW) {
             const int j0 = L::JW * (blk % L::NJB), l0 = L::LW * (blk / L::NJB);
             double acc[L::JW][L::LW] = {};
-            dot_block<L::JW, L::LW>(s + L::FT + j0 * SI, SI, s + L::VXX + l0 * SV, SV, SV, acc);   // Vxx pad column is zero
+            dot_block<L::JW, L::LW, SV>(s + L::FT + j0 * SI, SI, s + L::VXX + l0 * SV, SV, acc);   // Vxx pad column is zero
 #pragma unroll
             for (int jj = 0; jj < L::JW; ++jj)
 #pragma unroll
@@ -219,7 +242,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             const int code = ki[2 * SQ + t];
             const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
             double acc[3][3] = {};
-            dot_block<3, 3>(s + L::FT + a0 * SI, SI, s + L::WT + b0 * SI, SI, SI, acc);
+            dot_block<3, 3, SI>(s + L::FT + a0 * SI, SI, s + L::WT + b0 * SI, SI, acc);
             if (a0 == b0) {   // diagonal block: add D, keep it exactly symmetric
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -239,6 +262,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                         if (a0 != b0) s[L::Q + (b0 + j) * SQ + a0 + i] = acc[i][j];
                     }
         }
+        SDDP_TICK(13)
         if (wave == kLast) {
             for (int j = lane; j < NZ; j += kWave) {
                 double acc = s[L::REC + M::REC_G + j];
@@ -251,6 +275,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             }
         }
         __syncthreads();
+        SDDP_TICK(14)
         if (theta != 0.0) {   // exact second-order torque term (uniform switch)
             M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, SQ, theta, tid, kThreadsMW);
             __syncthreads();
@@ -396,6 +421,9 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
 
 // forward pass on 4 waves (called by every thread): lane l of every wave works on step length alpha_l.
 // Returns the cost of lane l's trajectory in wave 0 (other waves: unspecified).  Clobbers the WT and Q tiles.
+// Per knot: (A) wave 0 closes the previous knot, (B) every wave computes its rows of the feedback law, (C) wave 0 steps the
+// model while the other waves fetch the next knot's operands (gains, x_k, u_k, d_k, p_k: coalesced loads into LDS, read back
+// as broadcasts) and write the stored lane's x_k / u_k to HBM.
 template <class M, bool OPEN_LOOP>
 __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
                              const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
@@ -405,56 +433,64 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = NU * (NX + 1), SG = L::SG;
     constexpr int UPW = (NU + kWavesMW - 1) / kWavesMW;            // feedback rows per wave
     constexpr int kStagers = kThreadsMW - kWave;
+    constexpr int NSB = 2 * NX + NU + NP;
     const int lane = tid & (kWave - 1), wave = tid / kWave;
     const LdsCol X{s + L::RO_X + lane}, Y{s + L::RO_Y + lane}, U{s + L::RO_U + lane};
     double* kf = s + L::RO_G;                                      // staged gains of one knot: kff [NU]
     double* kb = s + L::RO_K;                                      //                           K [NU][SG]
-    auto stage_gains = [&](int k) {                                // waves 1..3: one knot's gains, coalesced, into LDS
-        const double* gk = gains + size_t(k) * NG;
-        for (int e = tid - kWave; e < NG; e += kStagers) {
-            const double v = gk[e];
-            if (e < NU) kf[e] = v;
-            else { const int i = (e - NU) / NX, j = (e - NU) % NX; kb[i * SG + j] = v; }
+    auto stage_knot = [&](int k) {                                 // waves 1..3
+        double* sb = s + L::RO_S + (k & 1) * L::SB_N;
+        if (!OPEN_LOOP) {
+            const double* gk = gains + size_t(k) * NG;
+            for (int e = tid - kWave; e < NG; e += kStagers) {
+                const double v = gk[e];
+                if (e < NU) kf[e] = v;
+                else { const int i = (e - NU) / NX, j = (e - NU) % NX; kb[i * SG + j] = v; }
+            }
+        }
+        for (int e = tid - kWave; e < NSB; e += kStagers) {
+            if (e < NX) sb[L::SB_X + e] = xs[k * NX + e];
+            else if (e < NX + NU) sb[L::SB_U + e - NX] = us[k * NU + e - NX];
+            else if (e < 2 * NX + NU) sb[L::SB_D + e - NX - NU] = dft[k * NX + e - NX - NU];
+            else sb[L::SB_P + e - 2 * NX - NU] = P[k * NP + e - 2 * NX - NU];
         }
     };
     __syncthreads();                                               // the tiles this pass aliases are no longer read
     if (wave == 0) {
         for (int i = 0; i < NX; ++i) Y[i] = x0[i];
-    } else if (!OPEN_LOOP) {
-        stage_gains(0);
+    } else {
+        stage_knot(0);
     }
     double J = 0.0;
     const double oma = 1.0 - alpha;
     for (int k = 0; k < N; ++k) {
         SDDP_TICK(8)
+        const double* sb = s + L::RO_S + (k & 1) * L::SB_N;
         // ---- A: wave 0 closes the previous knot: x_k = f(x_{k-1}, u_{k-1}) - (1 - alpha) d_{k-1}
         if (wave == 0) {
             if (k == 0 || OPEN_LOOP) { for (int i = 0; i < NX; ++i) X[i] = Y[i]; }
-            else { for (int i = 0; i < NX; ++i) X[i] = Y[i] - oma * dft[(k - 1) * NX + i]; }
+            else {
+                const double* dprev = s + L::RO_S + ((k - 1) & 1) * L::SB_N + L::SB_D;
+                for (int i = 0; i < NX; ++i) X[i] = Y[i] - oma * dprev[i];
+            }
         }
         __syncthreads();
+        SDDP_TICK(11)
         // ---- B: every wave computes UPW rows of u = u_k + alpha kff + K (x - x_k)
+        if (wave == kWavesMW - 1 && lane < NX) xn[k * NX + lane] = s[L::RO_X + lane * kWave + store_lane];
         {
             double dx[NX];
             if (!OPEN_LOOP) {
 #pragma unroll
-                for (int j = 0; j < NX; ++j) dx[j] = X[j];
-                if (wave == kWavesMW - 1 && lane == store_lane) {
-#pragma unroll
-                    for (int j = 0; j < NX; ++j) xn[k * NX + j] = dx[j];
-                }
-#pragma unroll
-                for (int j = 0; j < NX; ++j) dx[j] -= xs[k * NX + j];
-            } else if (wave == kWavesMW - 1 && lane == store_lane) {
-                for (int j = 0; j < NX; ++j) xn[k * NX + j] = X[j];
+                for (int j = 0; j < NX; ++j) dx[j] = X[j] - sb[L::SB_X + j];
             }
 #pragma unroll
             for (int r = 0; r < UPW; ++r) {
                 const int i = wave * UPW + r;
                 if (i < NU) {
-                    double acc = us[k * NU + i];
+                    double acc = sb[L::SB_U + i];
                     if (!OPEN_LOOP) {
-                        acc += alpha * kf[i];
+                        acc = fma(alpha, kf[i], acc);
                         const double* row = kb + i * SG;
 #pragma unroll
                         for (int j = 0; j + 1 < NX; j += 2) {
@@ -464,20 +500,26 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
                         if (NX & 1) acc = fma(row[NX - 1], dx[NX - 1], acc);
                     }
                     U[i] = acc;
-                    if (lane == store_lane) un[k * NU + i] = acc;
                 }
             }
         }
         __syncthreads();
         SDDP_TICK(10)
-        // ---- C: wave 0 steps the model; the other waves stage the next knot's gains
-        if (wave == 0) J += M::step(c, X, U, P + k * NP, k, Y);
-        else if (!OPEN_LOOP && k + 1 < N) stage_gains(k + 1);
+        // ---- C: wave 0 steps the model; the other waves write the stored lane's u_k and stage the next knot
+        if (wave == 0) {
+            J += M::step(c, X, U, sb + L::SB_P, k, Y);
+        } else {
+            if (tid - kWave < NU) un[k * NU + tid - kWave] = s[L::RO_U + (tid - kWave) * kWave + store_lane];
+            if (k + 1 < N) stage_knot(k + 1);
+        }
         SDDP_TICK(12)
     }
     if (wave == 0) {
         if (OPEN_LOOP) { for (int i = 0; i < NX; ++i) X[i] = Y[i]; }
-        else { for (int i = 0; i < NX; ++i) X[i] = Y[i] - oma * dft[(N - 1) * NX + i]; }
+        else {
+            const double* dprev = s + L::RO_S + ((N - 1) & 1) * L::SB_N + L::SB_D;
+            for (int i = 0; i < NX; ++i) X[i] = Y[i] - oma * dprev[i];
+        }
         J += M::term_cost(c, X, P + N * NP);
         if (lane == store_lane) {
             for (int i = 0; i < NX; ++i) xn[N * NX + i] = X[i];
