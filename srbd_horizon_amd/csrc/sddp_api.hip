@@ -95,10 +95,16 @@ constexpr bool use_mw() {
 #endif
 }
 
+// only the kernel a model actually uses is instantiated
+using KernelFn = void (*)(SolveArgs);
+template <class M> KernelFn pick_solve() { if constexpr (use_mw<M>()) return solve_kernel_mw<M>; else return solve_kernel<M>; }
+template <class M> KernelFn pick_backward() { if constexpr (use_mw<M>()) return backward_kernel_mw<M>; else return backward_kernel<M>; }
+template <class M> KernelFn pick_forward() { if constexpr (use_mw<M>()) return forward_kernel_mw<M>; else return forward_kernel<M>; }
+
 template <class M>
 int launch_solve(sddp_handle* h, const SolveArgs& a) {
     constexpr bool MW = use_mw<M>();
-    auto kern = MW ? solve_kernel_mw<M> : solve_kernel<M>;
+    KernelFn kern = pick_solve<M>();
     constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
     constexpr int threads = MW ? kThreadsMW : kWave;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -124,7 +130,7 @@ int launch_solve(sddp_handle* h, const SolveArgs& a) {
 template <class M>
 int launch_backward(sddp_handle* h, const SolveArgs& a) {
     constexpr bool MW = use_mw<M>();
-    auto kern = MW ? backward_kernel_mw<M> : backward_kernel<M>;
+    KernelFn kern = pick_backward<M>();
     constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(h->B), dim3(MW ? kThreadsMW : kWave), lds, h->stream, a);
@@ -134,7 +140,7 @@ int launch_backward(sddp_handle* h, const SolveArgs& a) {
 template <class M>
 int launch_forward(sddp_handle* h, const SolveArgs& a) {
     constexpr bool MW = use_mw<M>();
-    auto kern = MW ? forward_kernel_mw<M> : forward_kernel<M>;
+    KernelFn kern = pick_forward<M>();
     constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(h->B), dim3(MW ? kThreadsMW : kWave), lds, h->stream, a);

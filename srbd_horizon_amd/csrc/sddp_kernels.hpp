@@ -571,94 +571,6 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// forward pass for the WIDE models (srbd37: 37 + 37 + 24 doubles of per-lane state and a 24x37 gain product per knot):
-// the per-lane vectors x, dx / x+, u live in LDS columns (element i of lane l at [i*64 + l]: conflict-free, private to the
-// lane, no synchronisation) instead of registers that would spill to scratch.  The columns alias the WT and Q tiles, which
-// the sweep rebuilds at every knot; the WT pads it relies on are re-zeroed after the rollout.
-// -----------------------------------------------------------------------------------------------------------------
-template <class M>
-struct WideRollout {
-    using L = Lds<M>;
-    static constexpr int WORDS = (2 * M::NX + M::NU) * kWave;
-    static constexpr bool enabled = (M::NX > 16) && (WORDS <= L::NZP * L::NIP + L::NZP * L::NZP);
-};
-
-// wt: the instance's WT tile (the columns run on into the Q tile behind it); no barrier inside
-template <class M, bool OPEN_LOOP>
-__device__ double rollout_lds_core(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
-                                   const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
-                                   const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
-                                   double alpha, int store_lane, int lane, double* wt SDDP_T_ARG) {
-    constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = NU * (NX + 1);
-    const LdsCol X{wt + lane}, Y{wt + NX * kWave + lane}, U{wt + 2 * NX * kWave + lane};
-    for (int i = 0; i < NX; ++i) X[i] = x0[i];
-    double J = 0.0;
-    const double oma = 1.0 - alpha;
-    for (int k = 0; k < N; ++k) {
-        SDDP_TICK(8)
-        if (OPEN_LOOP) {
-            for (int i = 0; i < NU; ++i) U[i] = us[k * NU + i];
-        } else {
-            for (int j = 0; j < NX; ++j) Y[j] = X[j] - xs[k * NX + j];
-            const double* gk = gains + size_t(k) * NG;
-#pragma unroll 1
-            for (int i = 0; i < NU; ++i) {
-                double acc = us[k * NU + i] + alpha * gk[i];
-                const double* row = gk + NU + i * NX;
-#pragma unroll
-                for (int j = 0; j < NX; ++j) acc += row[j] * Y[j];
-                U[i] = acc;
-            }
-        }
-        SDDP_TICK(10)
-        if (lane == store_lane) {
-            for (int i = 0; i < NX; ++i) xn[k * NX + i] = X[i];
-            for (int i = 0; i < NU; ++i) un[k * NU + i] = U[i];
-        }
-        SDDP_TICK(11)
-        J += M::step(c, X, U, P + k * NP, k, Y);                 // Y <- x+ (dx is no longer needed)
-        SDDP_TICK(12)
-        if (OPEN_LOOP) {
-            for (int i = 0; i < NX; ++i) X[i] = Y[i];
-        } else {
-            for (int i = 0; i < NX; ++i) X[i] = Y[i] - oma * dft[k * NX + i];
-        }
-    }
-    J += M::term_cost(c, X, P + N * NP);
-    if (lane == store_lane) {
-        for (int i = 0; i < NX; ++i) xn[N * NX + i] = X[i];
-    }
-    return J;
-}
-
-template <class M, bool OPEN_LOOP>
-__device__ double rollout_lds(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
-                              const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
-                              const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
-                              double alpha, int store_lane, int lane, double* s) {
-    using L = Lds<M>;
-    SDDP_T_DECL
-    const double J = rollout_lds_core<M, OPEN_LOOP>(c, N, x0, P, xs, us, dft, gains, xn, un, alpha, store_lane, lane, s + L::WT SDDP_T_PASS);
-    __syncthreads();
-    for (int e = lane; e < L::NZP * L::NIP; e += kWave) s[L::WT + e] = 0.0;   // restore the zero pads of the WT tile
-    __syncthreads();
-    return J;
-}
-
-// picks the register or the LDS-column forward pass for the model
-template <class M, bool OPEN_LOOP>
-__device__ __forceinline__ double rollout_any(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
-                                              const double* __restrict__ xs, const double* __restrict__ us,
-                                              const double* __restrict__ dft, const double* __restrict__ gains,
-                                              double* __restrict__ xn, double* __restrict__ un, double alpha, int store_lane,
-                                              int lane, double* s) {
-    if constexpr (WideRollout<M>::enabled)
-        return rollout_lds<M, OPEN_LOOP>(c, N, x0, P, xs, us, dft, gains, xn, un, alpha, store_lane, lane, s);
-    else
-        return rollout<M, OPEN_LOOP>(c, N, x0, P, xs, us, dft, gains, xn, un, alpha, store_lane, lane, s);
-}
-
-// -----------------------------------------------------------------------------------------------------------------
 // fused persistent solve: one wavefront per MPC instance, all iterations in one launch (replaces ddp.py:101)
 // -----------------------------------------------------------------------------------------------------------------
 template <class M>
@@ -684,7 +596,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
     sweep_tables<M>(A.c, s, lane);
     // ---- starting point
     if (o.initial_rollout) {
-        J = rollout_any<M, true>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, lane, s);
+        J = rollout<M, true>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, lane, s);
         __syncthreads();
         for (int e = lane; e < (N + 1) * NX; e += kWave) xs[e] = xn[e];
         for (int e = lane; e < N * NX; e += kWave) dft[e] = 0.0;
@@ -729,7 +641,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
                     for (int j = 0; j < lane; ++j) a *= o.line_search_decrease_factor;
                     const bool valid = a >= o.alpha_converge_threshold;
                     SDDP_TICK(9)
-                    double Jl = rollout_any<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, guess, lane, s);
+                    double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, guess, lane, s);
                     SDDP_TICK(8)
                     ++rollouts;
                     const double pred = a * A1 + a * a * B2 - a * rho * gap;
@@ -742,7 +654,7 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
                         J_win = __shfl(Jl, win, kWave);
                         if (win != guess) {   // the stored trajectory is last iteration's winning lane: re-run only when it moves
                             __syncthreads();
-                            rollout_any<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, lane, s);
+                            rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, lane, s);
                             ++rollouts;
                         }
                         guess = win;
@@ -870,7 +782,7 @@ __global__ __launch_bounds__(kWave) void forward_kernel(SolveArgs A) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= A.B) return;
     const int N = A.N;
-    const double J = rollout_any<M, false>(A.c, N, A.x0 + size_t(b) * NX, A.P + size_t(b) * (N + 1) * NP,
+    const double J = rollout<M, false>(A.c, N, A.x0 + size_t(b) * NX, A.P + size_t(b) * (N + 1) * NP,
                                        A.xs + size_t(b) * (N + 1) * NX, A.us + size_t(b) * N * NU,
                                        A.dft + size_t(b) * N * NX, A.gains + size_t(b) * N * (NU * (NX + 1)),
                                        A.xn + size_t(b) * (N + 1) * NX, A.un + size_t(b) * N * NU, A.alpha, 0, lane, s);

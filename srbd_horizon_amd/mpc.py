@@ -76,6 +76,22 @@ class MpcLoop:
             self.solver.set_u_warmstart(np.repeat(s.getStaticInput()[:, None], ns, axis=1))
         return converged, sol
 
+    def reference_record(self, sol, node: int = 1, foot_frames=("left_sole_link", "right_sole_link")):
+        """ROS-free form of what the reference hands to CartesIO every tick (cartesio.py:58-79, called at
+        dsrbd_example.py:179-181): com position, base_link orientation (quaternion x,y,z,w) and one position per foot frame
+        -- the midpoint of a line foot's two contact points (cartesio.py:68-72), the contact itself for a point foot -- all
+        taken from the solution at ``node`` (the reference publishes node 1, the next tick's target)."""
+        rec = {"com": np.array(sol["r"][:, node]), "base_link": np.array(sol["o"][:, node]), "contacts": {}}
+        if self.model == "srbd37":
+            cm = self.srbd.contact_model
+            for leg, frame in enumerate(foot_frames):
+                pts = [sol["c" + str(leg * cm + j)][:, node] for j in range(cm)]
+                rec["contacts"][frame] = np.mean(pts, axis=0)
+        else:                                   # srbd13: contacts are parameters of the plan, not decision variables
+            for leg, frame in enumerate(foot_frames):
+                rec["contacts"][frame] = np.array(self.srbd.c[leg].values[:, node])
+        return rec
+
     def run(self, ticks: int, motion="walking", axes=(1.0, 0.0)):
         out = []
         for _ in range(ticks):

@@ -275,3 +275,10 @@ def test_receding_horizon_loop_runs_and_tracks():
         assert loop.wpg.step_counter == 6
         assert abs(loop.state[2] - 0.88) < 0.05                       # CoM height is tracked
         np.testing.assert_allclose(sol["x_opt"][:, 0], loop.solver._x0[0], atol=0)   # node 0 is the measured state
+        rec = loop.reference_record(sol)                              # what cartesio.py:58-79 publishes, without ROS
+        np.testing.assert_array_equal(rec["com"], sol["r"][:, 1])
+        np.testing.assert_array_equal(rec["base_link"], sol["o"][:, 1])
+        assert set(rec["contacts"]) == {"left_sole_link", "right_sole_link"}
+        if model == "srbd37":                                         # line foot: midpoint of its two contact points
+            np.testing.assert_allclose(rec["contacts"]["left_sole_link"], 0.5 * (sol["c0"][:, 1] + sol["c1"][:, 1]), atol=0)
+            np.testing.assert_allclose(rec["contacts"]["right_sole_link"], 0.5 * (sol["c2"][:, 1] + sol["c3"][:, 1]), atol=0)
