@@ -245,6 +245,20 @@ def main():
                                   "note": "srbd13 receding-horizon loop (mpc.MpcLoop = dsrbd_example.py:82-185 without ROS), B=1, "
                                           "N=30, walking forward, warm start = previous solution, 200 ticks after 20 warm-up; "
                                           "tick = shift + pack + sddp_solve (host pointers) + unpack + one simulator step"}
+        # the reference's own example loops (its real problem sizes, ns = 20, T = 1 s): dsrbd_example.py (srbd37) and
+        # dlip_example.py (lip30, configs[0]); 10 warm-up + 100 timed ticks each
+        out["ms_per_mpc_tick_reference_models"] = {}
+        for mname in ("srbd37", "lip30"):
+            lp = MpcLoop(mname, 20)
+            tms, its = [], []
+            for i in range(110):
+                t1 = time.perf_counter()
+                lp.tick("walking", (1.0, 0.0))
+                tms.append(1e3 * (time.perf_counter() - t1))
+                its.append(int(lp.solver.stats["iters"]))
+            out["ms_per_mpc_tick_reference_models"][mname] = {
+                "median": float(np.median(tms[10:])), "p99": float(np.percentile(tms[10:], 99)),
+                "solve_median": float(np.median(lp.solve_ms[10:])), "mean_iters": float(np.mean(its[10:]))}
         # PCIe-inclusive batch rate (host-pointer C-ABI call: params in, x/u/stats out) -- reported, never `value`
         eng.set_initial_state(batch["x0"])
         t_host = []

@@ -1,4 +1,5 @@
-"""Receding-horizon MPC loop: the body of reference python/dsrbd_example.py:82-185 with ROS stripped.
+"""Receding-horizon MPC loop: the body of reference python/dsrbd_example.py:82-185 (SRBD) and of
+python/dlip_example.py:89-160 (LIP, ``model="lip30"``) with ROS stripped.
 
 Per tick (dsrbd_example.py line numbers): setInitialState (:84) -> shift rdot_ref / w_ref / oref / orientation gain back by
 one node (:102-106, one slice move per parameter) -> assign the commanded velocity at node ns (:109-124) -> wpg.set(action)
@@ -15,7 +16,8 @@ import numpy as np
 from . import wpg as _wpg
 from .ddp import DDPSolver
 from .engine import eval_knots
-from .prb import SRBD13Problem, SRBDProblem
+from .problem import Parameter
+from .prb import LIPProblem, SRBD13Problem, SRBDProblem
 
 # reference option set (dsrbd_example.py:55-58)
 EXAMPLE_OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
@@ -35,6 +37,15 @@ class MpcLoop:
             self.srbd = SRBD13Problem()
             self.srbd.createSRBD13Problem(ns, T, robot)
             contact_model = 1
+        elif model == "lip30":
+            # dlip_example.py:49-52 builds an SRBD problem as well and hands ITS f / w_ref / orientation gain to the scheduler
+            # (:86-87); the LIP problem has no such parameters, so the scheduler writes into stand-ins that nothing reads
+            self.srbd = LIPProblem()
+            self.srbd.createLIPProblem(ns, T, robot)
+            contact_model = self.srbd.contact_model
+            self.srbd.f = None
+            self.srbd.w_ref = Parameter("w_ref", 3, ns + 1)
+            self.srbd.orientation_tracking_gain = Parameter("orientation_tracking_gain", 1, ns + 1)
         else:
             raise ValueError(model)
         self.model, self.ns = model, ns
@@ -53,7 +64,8 @@ class MpcLoop:
     def tick(self, motion: str = "standing", axes=(0.0, 0.0)):
         s, ns = self.srbd, self.ns
         self.solver.setInitialState(self.state)                                        # :84
-        for par in (s.rdot_ref, s.w_ref, s.oref, s.orientation_tracking_gain):         # :102-106
+        shifted = (s.rdot_ref,) if self.model == "lip30" else (s.rdot_ref, s.w_ref, s.oref, s.orientation_tracking_gain)
+        for par in shifted:                                                            # :102-106 / dlip_example.py:108-109
             par.values[:, :ns] = par.values[:, 1:ns + 1]
         a = 0.1 if motion == "standing" else 0.5                                       # :109-112
         s.rdot_ref.assign([a * axes[0], a * axes[1], 0.0], nodes=ns)                   # :119-122
@@ -66,7 +78,8 @@ class MpcLoop:
         p0 = s.prb.parameter_matrix()[0]
         f, _, _, _, _ = eval_knots(self.model, ns, [0], self.state[None], u0[None], p0[None], consts=s.prb.model_consts)
         self.state = f[0].copy()                                                       # :159 Euler step (same HIP model)
-        self.state[3:7] /= np.linalg.norm(self.state[3:7])                             # :160
+        if self.model != "lip30":
+            self.state[3:7] /= np.linalg.norm(self.state[3:7])                         # :160 (the LIP state has no quaternion)
         if self.warm_start == "shift":
             x, u = sol["x_opt"], sol["u_opt"]
             self.solver.set_x_warmstart(np.concatenate([x[:, 1:], x[:, -1:]], axis=1))
@@ -81,8 +94,9 @@ class MpcLoop:
         dsrbd_example.py:179-181): com position, base_link orientation (quaternion x,y,z,w) and one position per foot frame
         -- the midpoint of a line foot's two contact points (cartesio.py:68-72), the contact itself for a point foot -- all
         taken from the solution at ``node`` (the reference publishes node 1, the next tick's target)."""
-        rec = {"com": np.array(sol["r"][:, node]), "base_link": np.array(sol["o"][:, node]), "contacts": {}}
-        if self.model == "srbd37":
+        o = sol["o"][:, node] if "o" in sol else np.array([0.0, 0.0, 0.0, 1.0])          # dlip_example.py:145 publishes identity
+        rec = {"com": np.array(sol["r"][:, node]), "base_link": np.array(o), "contacts": {}}
+        if self.model in ("srbd37", "lip30"):
             cm = self.srbd.contact_model
             for leg, frame in enumerate(foot_frames):
                 pts = [sol["c" + str(leg * cm + j)][:, node] for j in range(cm)]

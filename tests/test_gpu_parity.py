@@ -263,22 +263,26 @@ def test_receding_horizon_loop_runs_and_tracks():
     """mpc.MpcLoop = the body of dsrbd_example.py:82-185 without ROS: a few walking ticks on the reference-faithful model
     (ns = 20, T = 1 s as in dsrbd_example.py:30-31) and on the metric model."""
     from srbd_horizon_amd.mpc import MpcLoop
-    for model, ns in (("srbd37", 20), ("srbd13", 30)):
+    for model, ns in (("srbd37", 20), ("srbd13", 30), ("lip30", 20)):
         loop = MpcLoop(model, ns)
         flags = loop.run(6, motion="walking", axes=(1.0, 0.0))
         sol = loop.solver.getSolutionDict()
         assert sol["x_opt"].shape == (loop.solver.state_size, ns + 1) and sol["u_opt"].shape == (loop.solver.input_size, ns)
-        assert set(["r", "o", "rdot", "w", "f0", "f1"]).issubset(sol.keys())
-        assert sol["r"].shape == (3, ns + 1) and sol["f0"].shape == (3, ns)
-        assert np.all(np.isfinite(loop.state)) and abs(np.linalg.norm(loop.state[3:7]) - 1.0) < 1e-12
+        assert np.all(np.isfinite(loop.state))
+        if model == "lip30":                                          # dlip_example.py:89-160
+            assert set(["r", "rdot", "z", "c0", "c3", "cddot0"]).issubset(sol.keys()) and sol["z"].shape == (3, ns)
+        else:
+            assert set(["r", "o", "rdot", "w", "f0", "f1"]).issubset(sol.keys())
+            assert sol["r"].shape == (3, ns + 1) and sol["f0"].shape == (3, ns)
+            assert abs(np.linalg.norm(loop.state[3:7]) - 1.0) < 1e-12
         assert len(loop.solve_ms) == 6 and all(np.isfinite(loop.solve_ms))
         assert loop.wpg.step_counter == 6
         assert abs(loop.state[2] - 0.88) < 0.05                       # CoM height is tracked
         np.testing.assert_allclose(sol["x_opt"][:, 0], loop.solver._x0[0], atol=0)   # node 0 is the measured state
         rec = loop.reference_record(sol)                              # what cartesio.py:58-79 publishes, without ROS
         np.testing.assert_array_equal(rec["com"], sol["r"][:, 1])
-        np.testing.assert_array_equal(rec["base_link"], sol["o"][:, 1])
+        np.testing.assert_array_equal(rec["base_link"], sol["o"][:, 1] if "o" in sol else [0.0, 0.0, 0.0, 1.0])
         assert set(rec["contacts"]) == {"left_sole_link", "right_sole_link"}
-        if model == "srbd37":                                         # line foot: midpoint of its two contact points
+        if model in ("srbd37", "lip30"):                              # line foot: midpoint of its two contact points
             np.testing.assert_allclose(rec["contacts"]["left_sole_link"], 0.5 * (sol["c0"][:, 1] + sol["c1"][:, 1]), atol=0)
             np.testing.assert_allclose(rec["contacts"]["right_sole_link"], 0.5 * (sol["c2"][:, 1] + sol["c3"][:, 1]), atol=0)

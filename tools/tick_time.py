@@ -5,7 +5,7 @@ from srbd_horizon_amd.mpc import MpcLoop
 
 model = sys.argv[1] if len(sys.argv) > 1 else "srbd37"
 ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 120
-loop = MpcLoop(model=model, ns=20)
+loop = MpcLoop(model=model, ns=int(sys.argv[3]) if len(sys.argv) > 3 else 20)
 for _ in range(10):
     loop.tick("walking", (1.0, 0.0))
 loop.solve_ms.clear()
