@@ -9,10 +9,14 @@ A "step" is one pass of the hot path over one batch of synthetic input: B = 1024
 GPU (BASELINE configs[2]; 8 GPUs x 1024 = configs[3]), N = 30 knots, nx = 13, nu = 6, each solved from a cold
 warm start (x = x0 at every node, u = static input) to convergence with the reference example's solver options
 (dsrbd_example.py:55-58).  Inputs are resident in HBM before the timed region; a step = reset warm start (D2D) + the
-fused persistent solve kernel (+ the RCCL all-gather of the solution records when N > 1).  Steps are issued round-robin on
-`--streams` (default 2) handles / HIP streams, i.e. two batches are in flight: a batch ends with its slowest instance and the
-SIMDs of finished instances would idle otherwise; `--streams 1` is strictly sequential (reported as an extra field).
-Weak scaling.
+fused persistent solve kernel (+ the RCCL all-gather of the solution records when N > 1).
+
+A batch ends with its slowest instance (93 DDP iterations; the mean is 16), so with ONE batch in flight the SIMDs of finished
+instances idle for most of the launch.  A fleet server keeps the GPU full by keeping several batches in flight: steps are
+issued round-robin on `--streams` (default 16) handles, each on its own HIP stream / hardware queue (GPU_MAX_HW_QUEUES is
+raised to 32 unless the environment sets it), with the kernel build that lets two instances share a SIMD
+(`waves_per_simd = 2`).  The strictly sequential figure (`--streams 1`, latency build) is reported beside it as
+`one_batch_in_flight_*`.  Weak scaling.
 
 Rank 0 prints ONE JSON line; `roofline` and `cpu_baseline` are defined in DESIGN.md ("Measurement").
 """
@@ -23,6 +27,10 @@ import sys
 import time
 
 import numpy as np
+
+# HIP maps streams onto this many hardware queues (default 4): batches on streams that share a queue would serialise.
+# Must be set before the HIP runtime initialises (i.e. before torch / the library are imported below).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -86,12 +94,13 @@ def cpu_baseline(N, B, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=1024, help="MPC instances per GPU")
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="batches in flight (handles on separate HIP streams)")
+    ap.add_argument("--streams", type=int, default=16, help="batches in flight (handles on separate HIP streams)")
+    ap.add_argument("--waves-per-simd", type=int, default=0, help="kernel build: 1 latency, 2 throughput; 0 = 2 when --streams > 1")
     ap.add_argument("--no-sequential", action="store_true")
     args = ap.parse_args()
 
@@ -125,6 +134,7 @@ def main():
     seeds = rank * B + np.arange(B)                        # instances are sharded contiguously across ranks
     batch = workload.make_batch("srbd13", N, seeds)
     opts = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsrbd_example.py:55-58
+    wps = args.waves_per_simd or (2 if S > 1 else 1)
     d_x0 = torch.from_numpy(batch["x0"]).to(dev)
     d_xs = torch.from_numpy(batch["xs"]).to(dev)
     d_us = torch.from_numpy(batch["us"]).to(dev)
@@ -134,7 +144,7 @@ def main():
     # the SIMDs of finished instances idle; a serving loop keeps the next batch resident.
     engs, streams, views, sends, gathers = [], [], [], [], []
     for i in range(S):
-        e = DdpEngine("srbd13", N, B, opts=opts)
+        e = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=wps))
         st_ = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
         e.use_torch_stream(st_)
         e.enable_timing(True)
@@ -145,8 +155,11 @@ def main():
     eng = engs[0]
 
     def step(i, engines=None):
-        k = i % (len(engines) if engines else S)
-        e, st_ = engs[k], streams[k]
+        if engines:                                             # strictly sequential extra measurement
+            k, e, st_ = 0, engines[0], streams[0]
+        else:
+            k = i % S
+            e, st_ = engs[k], streams[k]
         with torch.cuda.stream(st_):
             e.set_initial_state_device(d_x0)
             e.set_x_warmstart_device(d_xs)
@@ -204,20 +217,29 @@ def main():
                                "(BASELINE configs[2]; x8 GPUs = configs[3]), cold start, whole line-search ladder "
                                "(alpha=1..1e-12, 40 candidates) rolled out per iteration",
                    "batch_per_gpu": B, "horizon_N": N, "solver_opts": opts, "algorithm": "MS-DDP, Gauss-Newton Hessians",
-                   "batches_in_flight": S,
+                   "batches_in_flight": S, "waves_per_simd": wps, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "collective": "all_gather(solution records) per step" if world > 1 else "none"},
         "mean_iters": float(np.mean(iters)), "max_iters_hit_frac": float(np.mean(st["status"] == 1)),
         "converged_frac": float(np.mean(st["converged"] == 1)), "mean_rollouts": float(np.mean(rollouts)),
         "iterations_per_s": world * float(np.sum(iters)) * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic() if (B == 1024 and N == 30) else None, "kernel": "solve_kernel<SrbdModel<2,false>>", "kernel_ms": kms,
-                     "algorithmic_bytes_per_launch": abytes},
+                     "algorithmic_bytes_per_launch": abytes,
+                     "aggregate_achieved": world * B * args.steps / elapsed * (abytes / B) / 1e9,
+                     "note": "achieved = algorithmic bytes of one launch / its HIP-event duration (launches of different batches "
+                             "overlap, each lasts as long as its slowest instance); aggregate_achieved = solves/s x algorithmic "
+                             "bytes per solve, GB/s over all launches in flight"},
     }
     if rank == 0 and world == 1 and S > 1 and not args.no_sequential:
-        # Extra: strictly one batch in flight (the next step starts after the previous one's slowest instance has finished)
-        el1 = timed(args.steps, engines=[eng])
-        out["one_batch_in_flight_solves_per_s"] = B * args.steps / el1
-        out["one_batch_in_flight_ms_per_step"] = 1e3 * el1 / args.steps
+        # Extra: strictly one batch in flight (the next step starts after the previous one's slowest instance has finished),
+        # latency build of the kernel (full register file per instance)
+        e_lat = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
+        e_lat.use_torch_stream(streams[0])
+        n1 = min(args.steps, 6)
+        timed(1, engines=[e_lat])
+        el1 = timed(n1, engines=[e_lat])
+        out["one_batch_in_flight_solves_per_s"] = B * n1 / el1
+        out["one_batch_in_flight_ms_per_step"] = 1e3 * el1 / n1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ms / MPC tick, configs[1]: one instance, host-pointer call (PCIe included), cold start
         e1 = DdpEngine("srbd13", N, 1, opts=opts)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDDP_ABI_VERSION 1
+#define SDDP_ABI_VERSION 2
 
 /* model ids */
 #define SDDP_MODEL_SRBD13 0 /* nx=13 nu=6  np=19 : BASELINE.json metric model (contacts are per-knot parameters) */
@@ -49,6 +49,11 @@ typedef struct sddp_options {
     double mu_max;                      /* give up above this */
     int    second_order;                /* 1: add the exact bilinear-torque term v'.f_ux once full steps are accepted
                                            (DESIGN.md section 2); 0: plain Gauss-Newton / iLQR sweep */
+    int    waves_per_simd;              /* scheduling hint, no effect on results.  1 (default): the kernel build with the full
+                                           register file per instance -- shortest time for ONE batch.  2: the build capped at
+                                           half the register file, two instances resident per SIMD -- highest solves/s when
+                                           several batches are in flight on separate streams.  Only the
+                                           one-wavefront-per-instance kernel (srbd13) has both builds. */
 } sddp_options;
 
 /* replaces what the reference bakes into the CasADi graphs from the URDF and the rosparam server

@@ -25,7 +25,7 @@ class SddpOptions(C.Structure):
     _fields_ = [("max_iters", C.c_int), ("alpha_0", C.c_double), ("alpha_converge_threshold", C.c_double),
                 ("line_search_decrease_factor", C.c_double), ("beta", C.c_double), ("cost_reduction_ths", C.c_double),
                 ("mu0", C.c_double), ("initial_rollout", C.c_int), ("gap_tol", C.c_double), ("mu_min", C.c_double),
-                ("mu_max", C.c_double), ("second_order", C.c_int)]
+                ("mu_max", C.c_double), ("second_order", C.c_int), ("waves_per_simd", C.c_int)]
 
 
 class SddpModelConsts(C.Structure):
@@ -120,7 +120,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.sddp_abi_version() != 1:
+    if lib.sddp_abi_version() != 2:
         raise RuntimeError("libsddp_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -97,14 +97,17 @@ constexpr bool use_mw() {
 
 // only the kernel a model actually uses is instantiated
 using KernelFn = void (*)(SolveArgs);
-template <class M> KernelFn pick_solve() { if constexpr (use_mw<M>()) return solve_kernel_mw<M>; else return solve_kernel<M>; }
+template <class M> KernelFn pick_solve(int waves_per_simd) {
+    if constexpr (use_mw<M>()) return solve_kernel_mw<M>;
+    else return waves_per_simd >= 2 ? solve_kernel_w2<M> : solve_kernel<M>;
+}
 template <class M> KernelFn pick_backward() { if constexpr (use_mw<M>()) return backward_kernel_mw<M>; else return backward_kernel<M>; }
 template <class M> KernelFn pick_forward() { if constexpr (use_mw<M>()) return forward_kernel_mw<M>; else return forward_kernel<M>; }
 
 template <class M>
 int launch_solve(sddp_handle* h, const SolveArgs& a) {
     constexpr bool MW = use_mw<M>();
-    KernelFn kern = pick_solve<M>();
+    KernelFn kern = pick_solve<M>(h->opts.waves_per_simd);
     constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
     constexpr int threads = MW ? kThreadsMW : kWave;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -172,6 +175,7 @@ int validate_options(sddp_handle* h, const sddp_options& o) {
     if (!(o.alpha_0 > 0.0)) return fail(h, SDDP_ERR_ARG, "alpha_0 must be > 0");
     if (!(o.alpha_converge_threshold > 0.0)) return fail(h, SDDP_ERR_ARG, "alpha_converge_threshold must be > 0");
     if (!(o.mu_min > 0.0)) return fail(h, SDDP_ERR_ARG, "mu_min must be > 0");
+    if (o.waves_per_simd != 1 && o.waves_per_simd != 2) return fail(h, SDDP_ERR_ARG, "waves_per_simd must be 1 or 2");
     return SDDP_OK;
 }
 
@@ -204,6 +208,7 @@ void sddp_default_options(sddp_options* o) {
     o->mu_min = 1e-6;
     o->mu_max = 1e12;
     o->second_order = 1;
+    o->waves_per_simd = 1;
 }
 
 void sddp_default_consts(sddp_model_consts* c) {

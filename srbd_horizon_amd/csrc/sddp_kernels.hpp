@@ -527,7 +527,7 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
         }
         if (k + 1 < N) fetch(k + 1);
         __syncthreads();
-        double u[NU], xnext[NX];
+        double u[NU];
         if (OPEN_LOOP) {
 #pragma unroll
             for (int i = 0; i < NU; ++i) u[i] = ro[L::RO_U + i];
@@ -543,19 +543,16 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
                 u[i] = acc;
             }
         }
-        J += M::step(c, x, u, ro + L::RO_P, k, xnext);
         if (lane == store_lane) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) xn[k * NX + i] = x[i];
 #pragma unroll
             for (int i = 0; i < NU; ++i) un[k * NU + i] = u[i];
         }
-        if (OPEN_LOOP) {
+        J += M::step(c, x, u, ro + L::RO_P, k, x);               // in place: every component is read before it is written
+        if (!OPEN_LOOP) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = xnext[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = xnext[i] - oma * ro[L::RO_D + i];
+            for (int i = 0; i < NX; ++i) x[i] -= oma * ro[L::RO_D + i];
         }
         __syncthreads();
     }
@@ -574,8 +571,7 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
 // fused persistent solve: one wavefront per MPC instance, all iterations in one launch (replaces ddp.py:101)
 // -----------------------------------------------------------------------------------------------------------------
 template <class M>
-__global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
-    extern __shared__ __attribute__((aligned(16))) double s[];
+__device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NREC = M::NREC;
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= A.B) return;
@@ -703,6 +699,19 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
         st.iters = iters; st.converged = converged; st.status = status; st.rollouts = rollouts;
         A.stats[b] = st;
     }
+}
+
+
+// two builds of the same body: the register allocation is the only difference (sddp_options.waves_per_simd)
+template <class M>
+__global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double s[];
+    solve_body<M>(A, s);
+}
+template <class M>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2))) void solve_kernel_w2(SolveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double s[];
+    solve_body<M>(A, s);
 }
 
 // -----------------------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ from .problem import Problem
 # option keys the reference forwards to pyddp.DdpSolverOptions (ddp.py:16-35) + engine extras
 _REFERENCE_KEYS = ("max_iters", "alpha_0", "alpha_converge_threshold", "line_search_decrease_factor", "beta",
                    "cost_reduction_ths", "mu0")
-_EXTRA_KEYS = ("initial_rollout", "gap_tol", "mu_min", "mu_max", "second_order")
+_EXTRA_KEYS = ("initial_rollout", "gap_tol", "mu_min", "mu_max", "second_order", "waves_per_simd")
 
 
 class DDPSolver:
