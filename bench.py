@@ -223,7 +223,7 @@ def main():
         "converged_frac": float(np.mean(st["converged"] == 1)), "mean_rollouts": float(np.mean(rollouts)),
         "iterations_per_s": world * float(np.sum(iters)) * args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic() if (B == 1024 and N == 30) else None, "kernel": "solve_kernel<SrbdModel<2,false>>", "kernel_ms": kms,
+                     "traffic": pmc_traffic() if (B == 1024 and N == 30) else None, "kernel": ("solve_kernel_w2" if wps >= 2 else "solve_kernel") + "<SrbdModel<2,false>>", "kernel_ms": kms,
                      "algorithmic_bytes_per_launch": abytes,
                      "aggregate_achieved": world * B * args.steps / elapsed * (abytes / B) / 1e9,
                      "note": "achieved = algorithmic bytes of one launch / its HIP-event duration (launches of different batches "

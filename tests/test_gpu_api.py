@@ -87,3 +87,30 @@ def test_default_warm_start_when_none_is_passed():
     it1 = int(solver.stats["iters"])
     solver.solve()                                                   # the solver object keeps its solution as warm start
     assert int(solver.stats["iters"]) <= max(1, it1 // 2)
+
+
+def test_throughput_build_returns_the_same_results_as_the_latency_build():
+    """sddp_options.waves_per_simd only changes the register allocation of the fused kernel (two instances per SIMD): same
+    iterates, same iteration counts.  Also valid (and a no-op) on the models that have a single build."""
+    seeds = np.arange(96)
+    batch = workload.make_batch("srbd13", 30, seeds)
+    opts = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
+    res = []
+    for w in (1, 2):
+        eng = DdpEngine("srbd13", 30, len(seeds), opts=dict(opts, waves_per_simd=w))
+        eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+        x, u = eng.solve(batch["params"])
+        res.append((x, u, eng.stats.copy()))
+    (x1, u1, s1), (x2, u2, s2) = res
+    np.testing.assert_array_equal(s1["iters"], s2["iters"])
+    np.testing.assert_array_equal(s1["rollouts"], s2["rollouts"])
+    np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(u2, u1, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(s2["cost"], s1["cost"], rtol=1e-12)
+    with pytest.raises(RuntimeError, match="waves_per_simd"):
+        DdpEngine("srbd13", 30, 1, opts=dict(waves_per_simd=3))
+    b37 = workload.make_batch("srbd37", 20, [0, 1])
+    eng = DdpEngine("srbd37", 20, 2, opts=dict(opts, waves_per_simd=2))
+    eng.set_initial_state(b37["x0"]); eng.set_x_warmstart(b37["xs"]); eng.set_u_warmstart(b37["us"])
+    eng.solve(b37["params"])
+    assert np.all(eng.stats["converged"] == 1)
