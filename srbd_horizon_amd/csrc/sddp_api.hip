@@ -45,7 +45,7 @@ struct sddp_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // device buffers
-    double *x0 = nullptr, *P = nullptr, *xs = nullptr, *us = nullptr, *xn = nullptr, *un = nullptr, *dft = nullptr,
+    double *x0 = nullptr, *P = nullptr, *xs = nullptr, *us = nullptr, *xn = nullptr, *un = nullptr, *xc = nullptr, *uc = nullptr, *dft = nullptr,
            *gains = nullptr, *rec = nullptr, *scal = nullptr;
     sddp_stats* stats = nullptr;
     // timing
@@ -80,7 +80,7 @@ int fail(sddp_handle* h, int code, const std::string& msg) {
 SolveArgs make_args(sddp_handle* h, const double* d_params) {
     SolveArgs a;
     a.c = h->dc; a.o = h->opts; a.N = h->N; a.B = h->B;
-    a.x0 = h->x0; a.P = d_params; a.xs = h->xs; a.us = h->us; a.xn = h->xn; a.un = h->un; a.dft = h->dft;
+    a.x0 = h->x0; a.P = d_params; a.xs = h->xs; a.us = h->us; a.xn = h->xn; a.un = h->un; a.xc = h->xc; a.uc = h->uc; a.dft = h->dft;
     a.gains = h->gains; a.rec = h->rec; a.stats = h->stats; a.scal = h->scal; a.alpha = 0.0; a.mu = 0.0;
     return a;
 }
@@ -93,6 +93,15 @@ constexpr bool use_mw() {
 #else
     return Lds<M>::BYTES > 48 * 1024;
 #endif
+}
+
+bool model_uses_mw(int model_id) {
+    switch (model_id) {
+        case SDDP_MODEL_SRBD13: return use_mw<Srbd13>();
+        case SDDP_MODEL_SRBD37: return use_mw<Srbd37>();
+        case SDDP_MODEL_LIP30: return use_mw<Lip30>();
+        default: return false;
+    }
 }
 
 // only the kernel a model actually uses is instantiated
@@ -259,6 +268,10 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (e == hipSuccess) e = alloc((void**)&h->us, h->n_u() * D);
     if (e == hipSuccess) e = alloc((void**)&h->xn, h->n_x() * D);
     if (e == hipSuccess) e = alloc((void**)&h->un, h->n_u() * D);
+    if (!model_uses_mw(model_id)) {   // one-wave kernel: two sets of kSlots line-search candidates per instance
+        if (e == hipSuccess) e = alloc((void**)&h->xc, h->n_x() * 2 * kSlots * D);
+        if (e == hipSuccess) e = alloc((void**)&h->uc, h->n_u() * 2 * kSlots * D);
+    }
     if (e == hipSuccess) e = alloc((void**)&h->dft, size_t(batch) * N * d.nx * D);
     if (e == hipSuccess) e = alloc((void**)&h->gains, h->n_g() * D);
     if (e == hipSuccess) e = alloc((void**)&h->rec, size_t(batch) * (N + 1) * d.nrec * D);
@@ -279,7 +292,7 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
 void sddp_destroy(sddp_handle* h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->dft, h->gains, h->rec, h->scal, h->stats};
+    void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->xc, h->uc, h->dft, h->gains, h->rec, h->scal, h->stats};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);

@@ -24,6 +24,7 @@
 namespace sddp {
 
 constexpr int kWave = 64;
+constexpr int kSlots = 8;   // line-search candidates whose trajectories are kept per pass (one-wave kernel)
 constexpr int kScal = 16;  // doubles per instance in the scratch `scal` record (test kernels / diagnostic stamps)
 
 // Diagnostic build only (-DSDDP_STAMPS): per-phase shader-cycle sums, written to `scal`; never in the shipped library.
@@ -47,8 +48,10 @@ struct SolveArgs {
     const double* P;    // [B][N+1][NP]
     double* xs;         // [B][N+1][NX]  current iterate (in: warm start, out: solution)
     double* us;         // [B][N][NU]
-    double* xn;         // [B][N+1][NX]  candidate
+    double* xn;         // [B][N+1][NX]  candidate (4-wave kernels, single-phase test kernels)
     double* un;         // [B][N][NU]
+    double* xc;         // [B][2][kSlots][N+1][NX]  line-search candidates of the one-wave kernel: the first kSlots step lengths of
+    double* uc;         // [B][2][kSlots][N][NU]    a pass each keep their trajectory; two sets, written alternately
     double* dft;        // [B][N][NX]    defects d_{k+1} stored at k
     double* gains;      // [B][N][NU*(NX+1)]  kff (NU) then K (NU x NX, row-major)
     double* rec;        // [B][N+1][NREC]
@@ -493,9 +496,13 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
                           const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
                           const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
                           double alpha, int store_lane, int lane, double* s) {
+    // store_lane >= 0: that lane writes its trajectory to xn / un.  store_lane < 0: lanes 0 .. kSlots-1 each write theirs to
+    // slot `lane` of xn / un (slot strides (N+1) NX and N NU): same instruction count, no second pass to fetch the winner.
     using L = Lds<M>;
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = NU * (NX + 1), RG = (NG + kWave - 1) / kWave;
     double* ro = s + L::RO;
+    const bool storing = store_lane >= 0 ? lane == store_lane : lane < kSlots;
+    if (store_lane < 0 && storing) { xn += size_t(lane) * (N + 1) * NX; un += size_t(lane) * N * NU; }
     double x[NX];
     if (lane < NX) ro[L::RO_X + lane] = x0[lane];
     __syncthreads();
@@ -543,7 +550,7 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
                 u[i] = acc;
             }
         }
-        if (lane == store_lane) {
+        if (storing) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) xn[k * NX + i] = x[i];
 #pragma unroll
@@ -559,7 +566,7 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
     if (lane < NP) ro[L::RO_P + lane] = P[N * NP + lane];
     __syncthreads();
     J += M::term_cost(c, x, ro + L::RO_P);
-    if (lane == store_lane) {
+    if (storing) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[N * NX + i] = x[i];
     }
@@ -581,8 +588,12 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
     const double* P = A.P + size_t(b) * (N + 1) * NP;
     double* xs = A.xs + size_t(b) * (N + 1) * NX;
     double* us = A.us + size_t(b) * N * NU;
-    double* xn = A.xn + size_t(b) * (N + 1) * NX;
-    double* un = A.un + size_t(b) * N * NU;
+    // candidate sets: set w of this instance = kSlots trajectories; the pass of an iteration writes set `wr`, the current
+    // iterate lives in the other set (or in A.xs / A.us before the first accepted step)
+    const size_t XS = size_t(N + 1) * NX, US = size_t(N) * NU;
+    double* xc = A.xc + size_t(b) * 2 * kSlots * XS;
+    double* uc = A.uc + size_t(b) * 2 * kSlots * US;
+    int wr = 0;
     double* dft = A.dft + size_t(b) * N * NX;
     double* gains = A.gains + size_t(b) * N * (NU * (NX + 1));
     double* rec = A.rec + size_t(b) * (N + 1) * NREC;
@@ -592,9 +603,9 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
     sweep_tables<M>(A.c, s, lane);
     // ---- starting point
     if (o.initial_rollout) {
-        J = rollout<M, true>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, lane, s);
+        J = rollout<M, true>(A.c, N, x0, P, xs, us, dft, gains, xc, uc, 0.0, 0, lane, s);
         __syncthreads();
-        for (int e = lane; e < (N + 1) * NX; e += kWave) xs[e] = xn[e];
+        for (int e = lane; e < (N + 1) * NX; e += kWave) xs[e] = xc[e];
         for (int e = lane; e < N * NX; e += kWave) dft[e] = 0.0;
         __syncthreads();
     } else {
@@ -604,7 +615,7 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
         __syncthreads();
     }
     double mu = o.mu0, rho = 0.0, alpha = 0.0, expected = 0.0, theta = 0.0;
-    int iters = 0, converged = 0, status = 1, rollouts = 0, guess = 0;
+    int iters = 0, converged = 0, status = 1, rollouts = 0, win = 0;
     if (!(fabs(J) < 1e300)) { status = 3; }
     else
         while (iters < o.max_iters) {
@@ -637,7 +648,9 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
                     for (int j = 0; j < lane; ++j) a *= o.line_search_decrease_factor;
                     const bool valid = a >= o.alpha_converge_threshold;
                     SDDP_TICK(9)
-                    double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, guess, lane, s);
+                    double* xw = xc + size_t(wr) * kSlots * XS;
+                    double* uw = uc + size_t(wr) * kSlots * US;
+                    double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xw, uw, a, -1, lane, s);
                     SDDP_TICK(8)
                     ++rollouts;
                     const double pred = a * A1 + a * a * B2 - a * rho * gap;
@@ -645,20 +658,19 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
                     const bool good = valid && (fabs(Jl) < 1e300) && (dphi <= o.beta * pred + slack);
                     const unsigned long long mask = __ballot(good);
                     if (mask) {
-                        const int win = __ffsll((long long)mask) - 1;
+                        win = __ffsll((long long)mask) - 1;
                         a_win = __shfl(a, win, kWave);
                         J_win = __shfl(Jl, win, kWave);
-                        if (win != guess) {   // the stored trajectory is last iteration's winning lane: re-run only when it moves
+                        if (win >= kSlots) {   // the winner is not one of the kept candidates: roll it again into slot 0
                             __syncthreads();
-                            rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, lane, s);
+                            rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xw, uw, a, win, lane, s);
                             ++rollouts;
+                            win = 0;
                         }
-                        guess = win;
                         accepted = true;
                         break;
                     }
                     a_base = __shfl(a, kWave - 1, kWave) * o.line_search_decrease_factor;
-                    guess = 0;
                 }
                 if (accepted) break;
                 if (theta != 0.0) { theta = 0.0; continue; }                       // redo with the plain Gauss-Newton step
@@ -671,8 +683,9 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
             const double dJ = J - J_win;
             J = J_win;
             __syncthreads();
-            { double* t = xs; xs = xn; xn = t; }
-            { double* t = us; us = un; un = t; }
+            xs = xc + (size_t(wr) * kSlots + win) * XS;          // the accepted candidate becomes the iterate; next pass writes
+            us = uc + (size_t(wr) * kSlots + win) * US;          // the other set
+            wr ^= 1;
             const double oma = 1.0 - alpha;
             for (int e = lane; e < N * NX; e += kWave) dft[e] *= oma;
             gap *= oma;
