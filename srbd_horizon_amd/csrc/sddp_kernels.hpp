@@ -429,7 +429,8 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         __syncthreads();
         SDDP_TICK(5)
         if (!ok) return false;
-        // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + 1/2 (Qux^T K + K^T Qux): lower-triangle 2x2 blocks, mirrored
+        // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + Qux^T K.  Qux^T K = -Qux^T (Quu + mu I)^-1 Qux is symmetric, so only the lower
+        //      triangle is formed (2x2 blocks, one product per element) and mirrored; diagonal blocks are symmetrised
         if (lane < NX) {
             double acc = s[L::QV + lane];
 #pragma unroll
@@ -443,18 +444,16 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 const double qa = s[L::Q + a0 * NZP + NX + i], qb = s[L::Q + (a0 + 1) * NZP + NX + i];
-                const double qc = s[L::Q + c0 * NZP + NX + i], qd = s[L::Q + (c0 + 1) * NZP + NX + i];
-                const double ka = s[L::KT + a0 * NUP + i], kb = s[L::KT + (a0 + 1) * NUP + i];
                 const double kc = s[L::KT + c0 * NUP + i], kd = s[L::KT + (c0 + 1) * NUP + i];
-                v00 = fma(qc, ka, fma(qa, kc, v00));
-                v01 = fma(qd, ka, fma(qa, kd, v01));
-                v10 = fma(qc, kb, fma(qb, kc, v10));
-                v11 = fma(qd, kb, fma(qb, kd, v11));
+                v00 = fma(qa, kc, v00);
+                v01 = fma(qa, kd, v01);
+                v10 = fma(qb, kc, v10);
+                v11 = fma(qb, kd, v11);
             }
-            v00 = s[L::Q + a0 * NZP + c0] + 0.5 * v00;
-            v01 = s[L::Q + a0 * NZP + c0 + 1] + 0.5 * v01;
-            v10 = s[L::Q + (a0 + 1) * NZP + c0] + 0.5 * v10;
-            v11 = s[L::Q + (a0 + 1) * NZP + c0 + 1] + 0.5 * v11;
+            v00 += s[L::Q + a0 * NZP + c0];
+            v01 += s[L::Q + a0 * NZP + c0 + 1];
+            v10 += s[L::Q + (a0 + 1) * NZP + c0];
+            v11 += s[L::Q + (a0 + 1) * NZP + c0 + 1];
             if (a0 + 1 >= NX) { v10 = 0.0; v11 = 0.0; }
             if (c0 + 1 >= NX) { v01 = 0.0; v11 = 0.0; }
             if (a0 == c0) { const double off = 0.5 * (v01 + v10); v01 = v10 = off; }

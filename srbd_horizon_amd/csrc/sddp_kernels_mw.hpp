@@ -351,7 +351,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         }
         __syncthreads();
         SDDP_TICK(5)
-        // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + 1/2 (Qux^T K + K^T Qux): 2x2 lower-triangle blocks, mirrored
+        // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + Qux^T K (symmetric: lower triangle in 2x2 blocks, mirrored)
         if (wave == kLast && lane < NX) {
             double acc = s[L::QV + lane];
             for (int i = 0; i < NU; ++i) acc += s[L::Q + lane * SQ + NX + i] * s[L::KF + i];
@@ -365,18 +365,16 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
 #pragma unroll 4
             for (int i = 0; i < NU; ++i) {
                 const double qa = s[L::Q + a0 * SQ + NX + i], qb = s[L::Q + a1 * SQ + NX + i];
-                const double qc = s[L::Q + c0 * SQ + NX + i], qd = s[L::Q + c1 * SQ + NX + i];
-                const double ka = s[L::KT + a0 * SK + i], kb = s[L::KT + a1 * SK + i];
                 const double kc = s[L::KT + c0 * SK + i], kd = s[L::KT + c1 * SK + i];
-                v00 = fma(qc, ka, fma(qa, kc, v00));
-                v01 = fma(qd, ka, fma(qa, kd, v01));
-                v10 = fma(qc, kb, fma(qb, kc, v10));
-                v11 = fma(qd, kb, fma(qb, kd, v11));
+                v00 = fma(qa, kc, v00);
+                v01 = fma(qa, kd, v01);
+                v10 = fma(qb, kc, v10);
+                v11 = fma(qb, kd, v11);
             }
-            v00 = s[L::Q + a0 * SQ + c0] + 0.5 * v00;
-            v01 = s[L::Q + a0 * SQ + c1] + 0.5 * v01;
-            v10 = s[L::Q + a1 * SQ + c0] + 0.5 * v10;
-            v11 = s[L::Q + a1 * SQ + c1] + 0.5 * v11;
+            v00 += s[L::Q + a0 * SQ + c0];
+            v01 += s[L::Q + a0 * SQ + c1];
+            v10 += s[L::Q + a1 * SQ + c0];
+            v11 += s[L::Q + a1 * SQ + c1];
             if (a0 == c0) { const double off = 0.5 * (v01 + v10); v01 = v10 = off; }
             const bool ha = a0 + 1 < NX, hc = c0 + 1 < NX;
             s[L::VXX + a0 * SV + c0] = v00;
