@@ -118,7 +118,8 @@ struct Lds {
     static constexpr int DG = DS + NZP;            // constant diagonal, stage part   [NZP]
     static constexpr int LS = DG + NZP;            // extra-row weights, state / stage [NE] each
     static constexpr int LG = LS + ((NE + 1) & ~1);
-    static constexpr int KI = LG + ((NE + 1) & ~1);    // ints: dkind[NZP], dci[NZP], tri LUT
+    static constexpr int LAM = LG + ((NE + 1) & ~1);   // LS + LG: extra-row weights of a stage node k >= 1
+    static constexpr int KI = LAM + ((NE + 1) & ~1);   // ints: dkind[NZP], dci[NZP], tri LUT
     static constexpr int NBQ = NZP / 2, NTRIQ = NBQ * (NBQ + 1) / 2;
     static constexpr int NBV = NXP / 2, NTRIV = NBV * (NBV + 1) / 2;
     static constexpr int KI_INTS = 2 * NZP + NTRIQ + NTRIV;
@@ -208,6 +209,7 @@ __device__ void sweep_tables(const DevConsts& c, double* s, int lane) {
     for (int m = lane; m < NE; m += kWave) {
         s[L::LS + m] = M::lam_state(c, m);
         s[L::LG + m] = M::lam_stage(c, m);
+        s[L::LAM + m] = M::lam_state(c, m) + M::lam_stage(c, m);
     }
     // lower-triangle block LUTs: t -> (ba << 8) | bc with ba >= bc
     for (int t = lane; t < L::NTRIQ; t += kWave) {
@@ -257,6 +259,12 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             }
             s[L::VXX + e] = v;
         }
+        // extra-row part of WT = (V~ F~)^T for the nodes k >= 1: lambda_m Je[m][j].  Constant entries are written here once per
+        // sweep, the per-knot variable ones by expand_var together with F~^T; node 0 (other weights) rescales them below
+        for (int e = lane; e < NZ * NE; e += kWave) {
+            const int j = e / NE, m = e % NE;
+            s[L::WT + j * NIP + NX + m] = s[L::LAM + m] * s[L::FT + j * NIP + NX + m];
+        }
         __syncthreads();
     }
     // ---- prefetch knot N-1
@@ -286,7 +294,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         SDDP_TICK(1)
         const double state = k >= 1 ? 1.0 : 0.0;
         // ---- expand: variable entries of F~^T; v' = Vx + Vxx d ; gap terms
-        M::expand_var(c, s + L::REC, s + L::FT, NIP, lane);
+        M::expand_var(c, s + L::REC, s + L::FT, NIP, lane, kWave, s + L::WT, s + L::LAM);
         if (lane < NX) {
             double acc = 0.0;
 #pragma unroll
@@ -317,18 +325,22 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                double2_t w;
-                w.x = a0[jj];
-                w.y = (l0 + 1 < NX) ? a1[jj] : 0.0;
-                *reinterpret_cast<double2_t*>(s + L::WT + (j0 + jj) * NIP + l0) = w;
+                if (l0 + 1 < NX) {
+                    double2_t w;
+                    w.x = a0[jj];
+                    w.y = a1[jj];
+                    *reinterpret_cast<double2_t*>(s + L::WT + (j0 + jj) * NIP + l0) = w;
+                } else {
+                    s[L::WT + (j0 + jj) * NIP + l0] = a0[jj];        // odd NX: slot NX belongs to the first extra row
+                }
             }
         }
-        __syncthreads();
-        // extra rows: WT[j][NX+m] = lambda_m(k) * Je[m][j]   (after the block stores: slot NX may have been zeroed as a pad)
-        for (int e = lane; e < NZ * NE; e += kWave) {
-            const int j = e / NE, m = e % NE;
-            const double lam = state * s[L::LS + m] + s[L::LG + m];
-            s[L::WT + j * NIP + NX + m] = lam * s[L::FT + j * NIP + NX + m];
+        if (k == 0) {   // node 0 carries no state residuals: rescale the extra rows with the stage-only weights
+            __syncthreads();
+            for (int e = lane; e < NZ * NE; e += kWave) {
+                const int j = e / NE, m = e % NE;
+                s[L::WT + j * NIP + NX + m] = s[L::LG + m] * s[L::FT + j * NIP + NX + m];
+            }
         }
         __syncthreads();
         SDDP_TICK(3)

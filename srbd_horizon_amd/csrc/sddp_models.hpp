@@ -695,7 +695,9 @@ struct SrbdModel {
     __device__ __forceinline__ static void expand_var(const DevConsts& c, const double* rec, double* FT, int NIP, int lane) {
         expand_var(c, rec, FT, NIP, lane, 64);
     }
-    __device__ __forceinline__ static void expand_var(const DevConsts& c, const double* rec, double* FT, int NIP, int tid, int nthreads) {
+    // WT != nullptr: also writes lam[m] * entry into the extra-row part of (V~ F~)^T (one-wave kernel)
+    __device__ __forceinline__ static void expand_var(const DevConsts& c, const double* rec, double* FT, int NIP, int tid, int nthreads,
+                                                      double* WT = nullptr, const double* lam = nullptr) {
         for (int e = tid; e < NVAR; e += nthreads) {
             int row, col, row2 = -1;
             double val, raw = 0.0;
@@ -714,7 +716,10 @@ struct SrbdModel {
             }
             val = (row == col ? 1.0 : 0.0) + c.dt * raw;
             FT[col * NIP + row] = val;
-            if (row2 >= 0) FT[col * NIP + row2] = raw;
+            if (row2 >= 0) {
+                FT[col * NIP + row2] = raw;
+                if (WT) WT[col * NIP + row2] = lam[row2 - NX] * raw;
+            }
         }
     }
 
@@ -991,7 +996,8 @@ struct LipModel {
         return kind == 3 ? stage * 2 * c.w_pen * sw * sw : 0.0;
     }
     __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int) {}
-    __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int, int) {}
+    __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int, int, double* = nullptr,
+                                                      const double* = nullptr) {}
     __device__ __forceinline__ static void add_second_order(const DevConsts&, const double*, const double*, double*, int, double, int, int) {}
 
 };
