@@ -286,3 +286,47 @@ def test_receding_horizon_loop_runs_and_tracks():
         if model in ("srbd37", "lip30"):                              # line foot: midpoint of its two contact points
             np.testing.assert_allclose(rec["contacts"]["left_sole_link"], 0.5 * (sol["c0"][:, 1] + sol["c1"][:, 1]), atol=0)
             np.testing.assert_allclose(rec["contacts"]["right_sole_link"], 0.5 * (sol["c2"][:, 1] + sol["c3"][:, 1]), atol=0)
+
+
+def test_whole_bench_batch_matches_the_c_oracle():
+    """All 1024 instances of the bench batch (BASELINE configs[2]) against the plain-C restatement of the oracle
+    (oracle/c, pinned to the numpy oracle by tests/test_oracle_c.py): same iteration count and, at the north_star tolerance
+    (1e-4 l-inf), the same trajectory -- stragglers included (up to 93 iterations, step lengths down to 2^-9, i.e. the
+    line-search path whose winner is not one of the kept candidates)."""
+    from oracle import cport
+    N, B = 30, 1024
+    batch = workload.make_batch("srbd13", N, np.arange(B))
+    eng = DdpEngine("srbd13", N, B, opts=_opts())
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    st = eng.stats.copy()
+    xo, uo, so = cport.solve_batch(omodels.RobotConsts(**batch["consts"]), _oracle_opts(), batch["x0"], batch["params"],
+                                   batch["xs"], batch["us"], threads=8)
+    it_o = so[:, 1].astype(int)
+    same = st["iters"] == it_o
+    # chaotic early iterations of a few hard instances may pick another step length on a last-bit difference: allow 1 %
+    assert same.mean() >= 0.99, f"{(~same).sum()} instances with a different iteration count"
+    assert st["iters"].max() >= 60 and st["rollouts"].max() > st["iters"].max()       # the fallback path did run
+    ex = np.max(np.abs(x[same] - xo[same]), axis=(1, 2))
+    eu = np.max(np.abs(u[same] - uo[same]), axis=(1, 2))
+    assert ex.max() <= 1e-4 and eu.max() <= 1e-4, (ex.max(), eu.max())
+    np.testing.assert_allclose(st["cost"][same], so[same, 0], rtol=1e-8)
+    np.testing.assert_array_equal(st["converged"][same], so[same, 2].astype(int))
+
+
+@pytest.mark.parametrize("name,N,B", [("srbd13", 1, 3), ("srbd13", 2, 1), ("srbd13", 100, 2), ("lip30", 1, 2), ("srbd37", 2, 2),
+                                      ("lip30", 70, 1)])
+def test_extreme_horizons_and_ragged_batches(name, N, B):
+    """Shortest horizons, a horizon longer than a wavefront (the lane-per-knot phases wrap), odd batch sizes."""
+    batch = workload.make_batch(name, N, np.arange(B) + 3)
+    eng = DdpEngine(name, N, B, opts=_opts())
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    st = eng.stats.copy()
+    assert np.all(np.isfinite(x)) and np.all(np.isfinite(u))
+    m = _oracle_model(name)
+    for b in range(B):
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], _oracle_opts())
+        assert st["iters"][b] == r.iters and bool(st["converged"][b]) == r.converged
+        assert np.max(np.abs(x[b] - r.xs)) <= 1e-6 and np.max(np.abs(u[b] - r.us)) <= 1e-6
+        assert abs(st["cost"][b] - r.cost) <= 1e-9 * max(1.0, abs(r.cost))
