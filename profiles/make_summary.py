@@ -27,14 +27,30 @@ out["SQ"] = {k: sum(v) / len(v) for k, v in sq.items()}
 f, w = out["FETCH_SIZE"]["mean"], out["WRITE_SIZE"]["mean"]
 out["traffic_bytes_per_launch"] = (2 * f + w) * 1024
 out["traffic_bytes_per_launch_uncorrected"] = (f + w) * 1024
+# rocprofv3 per-dispatch durations of the traced run, split like bench.py splits them (warm-up launches are not in its HIP-event mean)
+tr = sorted(glob.glob(os.path.join(trace, "**", "*kernel_trace.csv"), recursive=True))
+if tr:
+    ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr[0])) if "solve_kernel" in r["Kernel_Name"])
+    dur = [(e - s0) / 1e6 for s0, e in ks]
+    tl0 = os.path.join(os.path.dirname(blog), "trace.log")
+    tj = json.loads([l for l in open(tl0) if l.startswith("{")][-1]) if os.path.exists(tl0) else None
+    nw = tj["warmup"] if tj else 0
+    out["traced_run"] = {"launches": len(dur), "warmup_launches": nw, "rocprof_mean_ms_all": sum(dur) / len(dur),
+                         "rocprof_mean_ms_timed": sum(dur[nw:]) / max(1, len(dur) - nw),
+                         "hip_event_mean_ms_timed": tj["roofline"]["kernel_ms"] if tj else None}
 out["note"] = ("rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_* each in its own run) of `python3 bench.py --steps 32 --warmup 16 "
                "--no-cpu-baseline --no-sequential` (16 batches in flight, the bench default); FETCH/WRITE_SIZE in KiB; gfx950 correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE "
                "doubled (calibrated for 16 B/lane streams; this kernel reads 8 B/lane, so the uncorrected figure is also given). "
                "Kernel = solve_kernel_w2<SrbdModel<2,false>>, B=1024, N=30; means over all dispatches of the run.")
 json.dump(out, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1)
 line = [l for l in open(blog) if l.startswith("{")][-1]
-open(os.path.join(out_dir, "bench_line.json"), "w").write(line)
 d = json.loads(line)
+d["roofline"]["traffic"] = out["traffic_bytes_per_launch"]      # the PMC passes of THIS collection (bench.py read the previous one)
+open(os.path.join(out_dir, "bench_line.json"), "w").write(json.dumps(d) + "\n")
+tl = os.path.join(os.path.dirname(blog), "trace.log")
+if os.path.exists(tl):                                          # the bench line of the traced run: its HIP-event kernel time
+    tline = [l for l in open(tl) if l.startswith("{")][-1]      # must agree with kernel_stats_bench.csv
+    open(os.path.join(out_dir, "bench_line_traced_run.json"), "w").write(tline)
 print({k: d.get(k) for k in ("value", "ms_per_step", "mean_iters", "mean_rollouts", "converged_frac", "iterations_per_s",
                               "pcie_inclusive_solves_per_s", "one_batch_in_flight_solves_per_s")})
 print(d["roofline"]); print(d.get("cpu_baseline")); print(d.get("ms_per_mpc_tick")); print(out["SQ"]); print(out["kernel"])
