@@ -255,7 +255,7 @@ def main():
         # ms / MPC tick as SURVEY 8(d) defines it: receding-horizon loop (param shift + pack + solve + unpack + simulate),
         # B = 1, warm-started from the previous tick, walking with a forward command; 20 warm-up + 200 timed ticks
         from srbd_horizon_amd.mpc import MpcLoop
-        loop = MpcLoop("srbd13", N)
+        loop = MpcLoop("srbd13", N, warm_start="device")
         tick_ms, solve_ms, its = [], [], []
         for i in range(220):
             t1 = time.perf_counter()
@@ -266,12 +266,13 @@ def main():
                                   "solve_median": float(np.median(loop.solve_ms[20:])), "mean_iters": float(np.mean(its[20:])),
                                   "note": "srbd13 receding-horizon loop (mpc.MpcLoop = dsrbd_example.py:82-185 without ROS), B=1, "
                                           "N=30, walking forward, warm start = previous solution, 200 ticks after 20 warm-up; "
-                                          "tick = shift + pack + sddp_solve (host pointers) + unpack + one simulator step"}
+                                          "tick = host scheduler + sddp_advance (device-side shift of parameters and warm start; last "
+                                          "parameter column and state over PCIe) + sddp_solve_resident + unpack + one simulator step"}
         # the reference's own example loops (its real problem sizes, ns = 20, T = 1 s): dsrbd_example.py (srbd37) and
         # dlip_example.py (lip30, configs[0]); 10 warm-up + 100 timed ticks each
         out["ms_per_mpc_tick_reference_models"] = {}
         for mname in ("srbd37", "lip30"):
-            lp = MpcLoop(mname, 20)
+            lp = MpcLoop(mname, 20, warm_start="device")
             tms, its = [], []
             for i in range(110):
                 t1 = time.perf_counter()

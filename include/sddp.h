@@ -127,6 +127,18 @@ int  sddp_enable_timing(sddp_handle* h, int on);
 /* sum and count of the solve-kernel durations (HIP events, one pair per launch) read at the last sddp_synchronize calls */
 int  sddp_kernel_time_stats(sddp_handle* h, double* sum_ms, long long* count, int reset);
 
+/* ---- receding horizon with device-resident data ------------------------------------------
+ * Per tick the reference shifts every parameter back by one node and writes node N (dsrbd_example.py:102-106, :119-122;
+ * wpg.py:74-99), and its solver object keeps the previous solution (dsrbd_example.py:59).  With these three calls only the new
+ * last parameter column and the measured state cross PCIe; the shift runs on the device. */
+/* upload the whole parameter tensor once (host pointer) */
+int  sddp_set_params(sddp_handle* h, const double* params /*[B][N+1][np]*/);
+/* one tick: params[k] <- params[k+1] (k < N), params[N] <- p_last;  warm start <- previous solution advanced by one knot
+ * (x[k] <- x[k+1], x[N] kept; u[k] <- u[k+1], u[N-1] kept);  initial state <- x0.  Host pointers. */
+int  sddp_advance(sddp_handle* h, const double* p_last /*[B][np]*/, const double* x0 /*[B][nx]*/);
+/* sddp_solve on the resident parameters */
+int  sddp_solve_resident(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats /*[B] or NULL*/);
+
 /* ---- building blocks exposed for parity tests (host pointers) ------------------------------------------------
  * The same device code the fused solve kernel uses, one phase at a time.
  * sddp_eval_knots: per-knot model evaluation (reference: CasADi evaluation of f_k / L_k and their derivatives

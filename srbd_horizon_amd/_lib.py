@@ -57,6 +57,9 @@ SYMBOLS = {
     "sddp_model_dims": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "sddp_default_options": (None, [_P(SddpOptions)]),
     "sddp_default_consts": (None, [_P(SddpModelConsts)]),
+    "sddp_set_params": (C.c_int, [_vp, _vp]),
+    "sddp_advance": (C.c_int, [_vp, _vp, _vp]),
+    "sddp_solve_resident": (C.c_int, [_vp, _vp, _vp, _vp]),
     "sddp_create": (C.c_int, [_P(_vp), C.c_int, C.c_int, C.c_int, _P(SddpOptions), _P(SddpModelConsts)]),
     "sddp_destroy": (None, [_vp]),
     "sddp_last_error": (C.c_char_p, [_vp]),

@@ -2,6 +2,7 @@
 // the `pyddp` surface bound by the reference adapter (python/ddp.py:93-94, :101, :106, :113-123).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -55,7 +56,8 @@ struct sddp_handle {
     double last_ms = 0.0, sum_ms = 0.0;
     long long n_ms = 0;
     std::string err;
-    bool have_x0 = false, have_xws = false, have_uws = false;
+    bool have_x0 = false, have_xws = false, have_uws = false, have_params = false;
+    double* tick_in = nullptr;      // [B][np + nx] staging of sddp_advance
 
     size_t n_x() const { return size_t(B) * (N + 1) * d.nx; }
     size_t n_u() const { return size_t(B) * N * d.nu; }
@@ -292,7 +294,7 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
 void sddp_destroy(sddp_handle* h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->xc, h->uc, h->dft, h->gains, h->rec, h->scal, h->stats};
+    void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->xc, h->uc, h->tick_in, h->dft, h->gains, h->rec, h->scal, h->stats};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -395,6 +397,46 @@ int sddp_solve(sddp_handle* h, const double* params, double* x_out, double* u_ou
     rc = sddp_synchronize(h);
     // the solution is the next warm start unless the caller overrides it (solver object persists across ticks,
     // dsrbd_example.py:59)
+    h->have_xws = true;
+    return rc;
+}
+
+int sddp_set_params(sddp_handle* h, const double* params) {
+    if (!h || !params) return SDDP_ERR_ARG;
+    HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_params = true;
+    return SDDP_OK;
+}
+
+int sddp_advance(sddp_handle* h, const double* p_last, const double* x0) {
+    if (!h || !p_last || !x0) return SDDP_ERR_ARG;
+    if (!h->have_params) return fail(h, SDDP_ERR_ARG, "sddp_set_params has not been called");
+    if (!h->have_xws || !h->have_uws) return fail(h, SDDP_ERR_ARG, "sddp_advance needs a previous solution or warm start");
+    if ((h->N + 1) * std::max(h->d.np, h->d.nx) > 8 * 256) return fail(h, SDDP_ERR_ARG, "horizon too long for sddp_advance");
+    if (!h->tick_in) HIP_TRY(h, hipMalloc((void**)&h->tick_in, size_t(h->B) * (h->d.np + h->d.nx) * sizeof(double)));
+    double* d_pl = h->tick_in;
+    double* d_x0 = h->tick_in + size_t(h->B) * h->d.np;
+    HIP_TRY(h, hipMemcpyAsync(d_pl, p_last, size_t(h->B) * h->d.np * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_x0, x0, size_t(h->B) * h->d.nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(advance_kernel, dim3(h->B), dim3(256), 0, h->stream, h->N, h->d.nx, h->d.nu, h->d.np, h->P, h->xs, h->us,
+                       h->x0, d_pl, d_x0);
+    HIP_TRY(h, hipGetLastError());
+    h->have_x0 = true;
+    return SDDP_OK;
+}
+
+int sddp_solve_resident(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats) {
+    int rc = check_ready(h);
+    if (rc != SDDP_OK) return rc;
+    if (!h->have_params) return fail(h, SDDP_ERR_ARG, "sddp_set_params has not been called");
+    if (!x_out || !u_out) return fail(h, SDDP_ERR_ARG, "NULL argument");
+    rc = sddp_solve_device(h, h->P);
+    if (rc != SDDP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(x_out, h->xs, h->n_x() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(u_out, h->us, h->n_u() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (stats) HIP_TRY(h, hipMemcpyAsync(stats, h->stats, size_t(h->B) * sizeof(sddp_stats), hipMemcpyDeviceToHost, h->stream));
+    rc = sddp_synchronize(h);
     h->have_xws = true;
     return rc;
 }

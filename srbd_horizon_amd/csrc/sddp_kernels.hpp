@@ -822,4 +822,34 @@ __global__ __launch_bounds__(kWave) void forward_kernel(SolveArgs A) {
     if (lane == 0) A.scal[size_t(b) * kScal] = J;
 }
 
+// receding-horizon tick on the device: shift parameters and warm start by one knot (one workgroup per instance; every element
+// is read before the barrier and written after it, so the in-place shift is safe)
+__global__ __launch_bounds__(256) void advance_kernel(int N, int nx, int nu, int np, double* __restrict__ P, double* __restrict__ xs,
+                                                      double* __restrict__ us, double* __restrict__ x0, const double* __restrict__ p_last,
+                                                      const double* __restrict__ x0_new) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double* Pb = P + size_t(b) * (N + 1) * np;
+    double* xb = xs + size_t(b) * (N + 1) * nx;
+    double* ub = us + size_t(b) * N * nu;
+    constexpr int R = 8;                                   // elements per thread and array: up to 2048 words
+    double rp[R], rx[R], ru[R];
+    const int np_all = (N + 1) * np, nx_all = (N + 1) * nx, nu_all = N * nu;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int e = tid + t * 256;
+        rp[t] = e < np_all ? (e + np < np_all ? Pb[e + np] : p_last[size_t(b) * np + (e - N * np)]) : 0.0;
+        rx[t] = e < nx_all ? xb[e + nx < nx_all ? e + nx : e] : 0.0;
+        ru[t] = e < nu_all ? ub[e + nu < nu_all ? e + nu : e] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int e = tid + t * 256;
+        if (e < np_all) Pb[e] = rp[t];
+        if (e < nx_all) xb[e] = rx[t];
+        if (e < nu_all) ub[e] = ru[t];
+    }
+    if (tid < nx) x0[size_t(b) * nx + tid] = x0_new[size_t(b) * nx + tid];
+}
+
 }  // namespace sddp

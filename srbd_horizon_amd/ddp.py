@@ -90,6 +90,36 @@ class DDPSolver:
         self.stats = self.ddp_solver.stats[0]
         return bool(self.stats["converged"])                                # ddp.py:106
 
+    def solve_receding(self, x0) -> bool:
+        """One tick of the receding-horizon loop with device-resident data.
+
+        Contract: since the previous call the caller has shifted every parameter back by one node and assigned node N -- which
+        is all dsrbd_example.py:102-131 / wpg.py:74-99 ever do.  Then only the last parameter column and ``x0`` cross PCIe; the
+        engine shifts its resident parameter tensor and warm-starts from its previous solution advanced by one knot.  Same
+        result as ``setInitialState(x0)`` + shifted ``set_*_warmstart`` + ``solve()`` (tests/test_gpu_api.py)."""
+        x0 = np.asarray(x0, dtype=float).reshape(1, self.state_size)
+        self._x0 = x0.copy()
+        pm = self.prb.parameter_matrix()
+        if not getattr(self, "_resident", False):
+            self.setInitialState(x0)
+            if not self._have_u:
+                self.ddp_solver.set_u_warmstart(np.zeros((1, self.prb.nodes - 1, self.input_size)))
+                self._have_u = True
+            if not self._have_x:
+                self.ddp_solver.set_x_warmstart(np.repeat(self._x0[:, None, :], self.prb.nodes, axis=1))
+                self._have_x = True
+            self.ddp_solver.set_params(pm[None])
+            self._resident = True
+        else:
+            self.ddp_solver.advance(pm[-1][None], x0)
+        x, u = self.ddp_solver.solve_resident()
+        x, u = np.ascontiguousarray(x[0].T), np.ascontiguousarray(u[0].T)
+        self.var_solution = self._createVarSolDict(x, u)
+        self.var_solution["x_opt"] = x
+        self.var_solution["u_opt"] = u
+        self.stats = self.ddp_solver.stats[0]
+        return bool(self.stats["converged"])
+
     def getSolutionDict(self):
         return self.var_solution
 

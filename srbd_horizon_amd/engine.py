@@ -78,6 +78,26 @@ class DdpEngine:
         self.stats = st
         return x, u
 
+    # ---- receding horizon with device-resident parameters / warm start -----------------------------
+    def set_params(self, params):
+        p = self._c(params, (self.B, self.N + 1, self.np_))
+        self._chk(self.lib.sddp_set_params(self.h, _lib.ptr(p)))
+
+    def advance(self, p_last, x0):
+        """One tick on the device: parameters and previous solution shifted back by one knot, ``p_last`` written at node N,
+        ``x0`` set as the initial state."""
+        pl = self._c(p_last, (self.B, self.np_))
+        x = self._c(x0, (self.B, self.nx))
+        self._chk(self.lib.sddp_advance(self.h, _lib.ptr(pl), _lib.ptr(x)))
+
+    def solve_resident(self):
+        x = np.empty((self.B, self.N + 1, self.nx))
+        u = np.empty((self.B, self.N, self.nu))
+        st = np.zeros(self.B, dtype=_lib.STATS_DTYPE)
+        self._chk(self.lib.sddp_solve_resident(self.h, _lib.ptr(x), _lib.ptr(u), _lib.ptr(st)))
+        self.stats = st
+        return x, u
+
     def is_converged(self):
         f = np.zeros(self.B, dtype=np.int32)
         self._chk(self.lib.sddp_is_converged(self.h, _lib.ptr(f)))

@@ -27,7 +27,9 @@ class MpcLoop:
     def __init__(self, model: str = "srbd37", ns: int = 20, T: float | None = None, opts: dict | None = None, robot=None,
                  warm_start: str = "shift"):
         """warm_start: "shift" = previous solution advanced by one knot (last knot repeated),
-        "previous" = previous solution as is (what a stateful pyddp object would keep), "reset" = x0 repeated / static input."""
+        "device" = the same, with the parameter tensor and the warm start resident on the GPU and shifted there (only the new
+        last parameter column and the state cross PCIe), "previous" = previous solution as is (what a stateful pyddp object
+        would keep), "reset" = x0 repeated / static input."""
         T = ns * 0.05 if T is None else T                              # wpg hard-codes dt = 0.05 (wpg.py:20)
         if model == "srbd37":
             self.srbd = SRBDProblem()
@@ -63,7 +65,8 @@ class MpcLoop:
 
     def tick(self, motion: str = "standing", axes=(0.0, 0.0)):
         s, ns = self.srbd, self.ns
-        self.solver.setInitialState(self.state)                                        # :84
+        if self.warm_start != "device":
+            self.solver.setInitialState(self.state)                                    # :84
         shifted = (s.rdot_ref,) if self.model == "lip30" else (s.rdot_ref, s.w_ref, s.oref, s.orientation_tracking_gain)
         for par in shifted:                                                            # :102-106 / dlip_example.py:108-109
             par.values[:, :ns] = par.values[:, 1:ns + 1]
@@ -71,7 +74,10 @@ class MpcLoop:
         s.rdot_ref.assign([a * axes[0], a * axes[1], 0.0], nodes=ns)                   # :119-122
         self.wpg.set({"walking": "step", "jumping": "jump"}.get(motion, "standing"))   # :126-131
         t0 = time.perf_counter()                                                       # :134 tic()
-        converged = self.solver.solve()                                                # :135
+        if self.warm_start == "device":
+            converged = self.solver.solve_receding(self.state)                         # :84 + :135, device-resident data
+        else:
+            converged = self.solver.solve()                                            # :135
         self.solve_ms.append(1e3 * (time.perf_counter() - t0))                         # :136 toc()
         sol = self.solver.getSolutionDict()                                            # :137
         u0 = sol["u_opt"][:, 0]                                                        # :158

@@ -114,3 +114,22 @@ def test_throughput_build_returns_the_same_results_as_the_latency_build():
     eng.set_initial_state(b37["x0"]); eng.set_x_warmstart(b37["xs"]); eng.set_u_warmstart(b37["us"])
     eng.solve(b37["params"])
     assert np.all(eng.stats["converged"] == 1)
+
+
+@pytest.mark.parametrize("model,ns", [("srbd13", 30), ("srbd37", 20), ("lip30", 20)])
+def test_device_resident_receding_horizon_equals_the_host_shift(model, ns):
+    """sddp_set_params / sddp_advance / sddp_solve_resident: shifting the parameter tensor and the warm
+    start on the device gives the same ticks as shifting them on the host and passing them through sddp_solve."""
+    from srbd_horizon_amd.mpc import MpcLoop
+    host, dev = MpcLoop(model, ns, warm_start="shift"), MpcLoop(model, ns, warm_start="device")
+    for t in range(8):
+        motion = "walking" if t < 6 else "standing"
+        ch, sh = host.tick(motion, (1.0, 0.5))
+        cd, sd = dev.tick(motion, (1.0, 0.5))
+        assert ch == cd and host.solver.stats["iters"] == dev.solver.stats["iters"]
+        np.testing.assert_array_equal(sd["x_opt"], sh["x_opt"])
+        np.testing.assert_array_equal(sd["u_opt"], sh["u_opt"])
+        np.testing.assert_array_equal(dev.state, host.state)
+    e = DdpEngine(model, ns, 1)
+    with pytest.raises(RuntimeError, match="sddp_set_params"):
+        e.advance(np.zeros((1, e.np_)), np.zeros((1, e.nx)))
