@@ -413,7 +413,7 @@ int sddp_advance(sddp_handle* h, const double* p_last, const double* x0) {
     if (!h || !p_last || !x0) return SDDP_ERR_ARG;
     if (!h->have_params) return fail(h, SDDP_ERR_ARG, "sddp_set_params has not been called");
     if (!h->have_xws || !h->have_uws) return fail(h, SDDP_ERR_ARG, "sddp_advance needs a previous solution or warm start");
-    if ((h->N + 1) * std::max(h->d.np, h->d.nx) > 8 * 256) return fail(h, SDDP_ERR_ARG, "horizon too long for sddp_advance");
+    if ((h->N + 1) * std::max(h->d.np, h->d.nx) > kAdvanceWords) return fail(h, SDDP_ERR_ARG, "horizon too long for sddp_advance");
     if (!h->tick_in) HIP_TRY(h, hipMalloc((void**)&h->tick_in, size_t(h->B) * (h->d.np + h->d.nx) * sizeof(double)));
     double* d_pl = h->tick_in;
     double* d_x0 = h->tick_in + size_t(h->B) * h->d.np;

@@ -239,6 +239,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
     constexpr int NXP = L::NXP, NIP = L::NIP, NZP = L::NZP, NUP = L::NUP;
     constexpr int NCOL = NU + 1 + NX;
     constexpr int RREC = (NREC + kWave - 1) / kWave;
+    constexpr bool PADROW = (NXP > NX);      // odd NX: the pad row of the Vxx tile carries v' through the W product
     static_assert(NCOL <= kWave, "one lane per augmented column");
     static_assert(NX <= kWave && NP <= kWave, "one lane per state row / parameter");
     const int* ki = reinterpret_cast<const int*>(s + L::KI);
@@ -304,6 +305,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             }
             const double d = s[L::DK + lane], vx = s[L::VX + lane];
             s[L::VP + lane] = vx + acc;
+            if (PADROW) s[L::VXX + NX * NXP + lane] = vx + acc;   // pad row of Vxx := v': the W product then yields F^T v'
             G1 = fma(d, vx, G1);                 // per-lane partial sums, reduced once after the sweep
             G2 = fma(0.5 * d, acc, G2);
         }
@@ -331,7 +333,8 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
                     w.y = a1[jj];
                     *reinterpret_cast<double2_t*>(s + L::WT + (j0 + jj) * NIP + l0) = w;
                 } else {
-                    s[L::WT + (j0 + jj) * NIP + l0] = a0[jj];        // odd NX: slot NX belongs to the first extra row
+                    s[L::WT + (j0 + jj) * NIP + l0] = a0[jj];        // odd NX: slot NX belongs to the first extra row;
+                    if (j0 + jj < NZ) s[L::QV + j0 + jj] = s[L::REC + M::REC_G + j0 + jj] + a1[jj];   // row NX of Vxx holds v'
                 }
             }
         }
@@ -377,14 +380,16 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
                 *reinterpret_cast<double2_t*>(s + L::Q + (c0 + 1) * NZP + a0) = m1;
             }
         }
-        for (int j = lane; j < NZ; j += kWave) {
-            double acc = s[L::REC + M::REC_G + j];
+        if (!PADROW) {
+            for (int j = lane; j < NZ; j += kWave) {
+                double acc = s[L::REC + M::REC_G + j];
 #pragma unroll
-            for (int m = 0; m < NXP; m += 2) {
-                const double2_t f = lds2(s + L::FT + j * NIP + m), v = lds2(s + L::VP + m);
-                acc = fma(f.y, (m + 1 < NX) ? v.y : 0.0, fma(f.x, (m < NX) ? v.x : 0.0, acc));
+                for (int m = 0; m < NXP; m += 2) {
+                    const double2_t f = lds2(s + L::FT + j * NIP + m), v = lds2(s + L::VP + m);
+                    acc = fma(f.y, (m + 1 < NX) ? v.y : 0.0, fma(f.x, (m < NX) ? v.x : 0.0, acc));
+                }
+                s[L::QV + j] = acc;
             }
-            s[L::QV + j] = acc;
         }
         __syncthreads();
         if (theta != 0.0) {   // exact second-order torque term (wave-uniform switch)
@@ -394,18 +399,17 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         SDDP_TICK(4)
         // ---- [k K] = -Quu^-1 [Qu Qux]: Gauss-Jordan, lane j owns column j of [Quu+mu I | Qu | Qux]
         double a[NU];
-        if (lane < NCOL) {
+        {
+            // column of Q this lane reads (any valid one for lane NU, which takes q instead; lanes >= NCOL are zeroed)
+            const int qcol = lane < NU ? NX + lane : (lane > NU && lane < NCOL ? lane - NU - 1 : 0);
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                double v;
-                if (lane < NU) v = s[L::Q + (NX + i) * NZP + NX + lane] + (i == lane ? mu : 0.0);
-                else if (lane == NU) v = s[L::QV + NX + i];
-                else v = s[L::Q + (NX + i) * NZP + (lane - NU - 1)];
-                a[i] = v;
+                const double qv = s[L::QV + NX + i];
+                double v = s[L::Q + (NX + i) * NZP + qcol];
+                v = lane == NU ? qv : v;
+                v += (i == lane) ? mu : 0.0;
+                a[i] = lane < NCOL ? v : 0.0;
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NU; ++i) a[i] = 0.0;
         }
         double qu_abs = 0.0, qu_save[NU];
 #pragma unroll
@@ -822,6 +826,8 @@ __global__ __launch_bounds__(kWave) void forward_kernel(SolveArgs A) {
     if (lane == 0) A.scal[size_t(b) * kScal] = J;
 }
 
+constexpr int kAdvanceWords = 4096;   // longest array advance_kernel shifts in one workgroup: (N+1) * max(nx, np) words
+
 // receding-horizon tick on the device: shift parameters and warm start by one knot (one workgroup per instance; every element
 // is read before the barrier and written after it, so the in-place shift is safe)
 __global__ __launch_bounds__(256) void advance_kernel(int N, int nx, int nu, int np, double* __restrict__ P, double* __restrict__ xs,
@@ -831,7 +837,7 @@ __global__ __launch_bounds__(256) void advance_kernel(int N, int nx, int nu, int
     double* Pb = P + size_t(b) * (N + 1) * np;
     double* xb = xs + size_t(b) * (N + 1) * nx;
     double* ub = us + size_t(b) * N * nu;
-    constexpr int R = 8;                                   // elements per thread and array: up to 2048 words
+    constexpr int R = kAdvanceWords / 256;                 // elements per thread and array
     double rp[R], rx[R], ru[R];
     const int np_all = (N + 1) * np, nx_all = (N + 1) * nx, nu_all = N * nu;
 #pragma unroll
