@@ -426,14 +426,17 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
 #pragma unroll
             for (int i = 0; i < NU; ++i) a[i] = (i == p) ? t : fma(-pv[i], t, a[i]);
         }
-        // a = Quu^-1 * column ; publish kff and K^T (negated)
-        if (lane == NU) {
+        // a = Quu^-1 * column ; publish kff and K^T (negated) in LDS, and the gains to HBM/L2 straight from the registers:
+        // kff (NU) then K (NU x NX) row-major; row i of K is one contiguous store of the NX column lanes
+        if (lane >= NU && lane < NCOL) {
+            double* dst = lane == NU ? s + L::KF : s + L::KT + (lane - NU - 1) * NUP;            // KF follows KT: one region
+            double* gk = gains + size_t(k) * (NU * (NX + 1)) + (lane == NU ? 0 : NU + (lane - NU - 1));
+            const int gstride = lane == NU ? 1 : NX;
 #pragma unroll
-            for (int i = 0; i < NU; ++i) s[L::KF + i] = -a[i];
-        }
-        if (lane > NU && lane < NCOL) {
-#pragma unroll
-            for (int i = 0; i < NU; ++i) s[L::KT + (lane - NU - 1) * NUP + i] = -a[i];
+            for (int i = 0; i < NU; ++i) {
+                dst[i] = -a[i];
+                gk[i * gstride] = -a[i];
+            }
         }
         // dV1 += kff . Qu   (dV2 = 1/2 kff^T Quu kff = -1/2 dV1 exactly, not accumulated separately)
         double dv = 0.0;
@@ -483,14 +486,6 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
                 *reinterpret_cast<double2_t*>(s + L::VXX + c0 * NXP + a0) = m0;
                 *reinterpret_cast<double2_t*>(s + L::VXX + (c0 + 1) * NXP + a0) = m1;
             }
-        }
-        // ---- gains to HBM/L2: kff (NU) then K (NU x NX) row-major, one coalesced wave-wide store per 64 words
-        double* gk = gains + size_t(k) * (NU * (NX + 1));
-        for (int e = lane; e < NU * (NX + 1); e += kWave) {
-            double v;
-            if (e < NU) v = s[L::KF + e];
-            else { const int i = (e - NU) / NX, j = (e - NU) % NX; v = s[L::KT + j * NUP + i]; }
-            gk[e] = v;
         }
         __syncthreads();
         SDDP_TICK(6)
