@@ -245,6 +245,14 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
     const int* ki = reinterpret_cast<const int*>(s + L::KI);
     dV1 = G1 = G2 = qu_inf = 0.0;
     bool ok = true;
+    // the blocks this lane owns in the Q and Vxx phases never change: read the block LUT once per sweep, not once per knot
+    // (one dependent LDS round trip less in each of the two phases)
+    constexpr int PQ = (L::NTRIQ + kWave - 1) / kWave, PV = (L::NTRIV + kWave - 1) / kWave;
+    int codeq[PQ], codev[PV];
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) codeq[q] = (lane + q * kWave < L::NTRIQ) ? ki[2 * NZP + lane + q * kWave] : 0;
+#pragma unroll
+    for (int q = 0; q < PV; ++q) codev[q] = (lane + q * kWave < L::NTRIV) ? ki[2 * NZP + L::NTRIQ + lane + q * kWave] : 0;
     // ---- terminal node: Vx = lx_N, Vxx = lxx_N = diag(D_state) + Je^T Lambda_state Je  (ddp.py:216-226)
     {
         const double* rN = rec + size_t(N) * NREC;
@@ -348,8 +356,10 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         __syncthreads();
         SDDP_TICK(3)
         // ---- Q = diag(D) + F~^T (V~ F~): lower-triangle 2x2 blocks, mirrored ; q = g + F^T v'
-        for (int t = lane; t < L::NTRIQ; t += kWave) {
-            const int code = ki[2 * NZP + t];
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            if (lane + q * kWave >= L::NTRIQ) break;
+            const int code = codeq[q];
             const int a0 = 2 * (code >> 8), c0 = 2 * (code & 255);
             double q00 = 0, q01 = 0, q10 = 0, q11 = 0;
 #pragma unroll
@@ -456,8 +466,10 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             for (int i = 0; i < NU; ++i) acc += s[L::Q + lane * NZP + NX + i] * s[L::KF + i];
             s[L::VX + lane] = acc;
         }
-        for (int t = lane; t < L::NTRIV; t += kWave) {
-            const int code = ki[2 * NZP + L::NTRIQ + t];
+#pragma unroll
+        for (int q = 0; q < PV; ++q) {
+            if (lane + q * kWave >= L::NTRIV) break;
+            const int code = codev[q];
             const int a0 = 2 * (code >> 8), c0 = 2 * (code & 255);
             double v00 = 0, v01 = 0, v10 = 0, v11 = 0;
 #pragma unroll
