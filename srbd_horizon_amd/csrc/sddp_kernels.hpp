@@ -531,12 +531,30 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = ro[L::RO_X + i];
     __syncthreads();
-    double r_x = 0, r_u = 0, r_p = 0, r_d = 0, r_g[RG];
+    // knot operands x_k | u_k | p_k | d_k: when they fit one wave (2 NX + NU + NP <= 64) every lane owns ONE word of the knot:
+    // its source pointer / knot stride / LDS slot are fixed for the whole pass, so a knot costs one load and one LDS store
+    // (plus the gain rows) instead of four masked pairs
+    constexpr bool MERGED = !OPEN_LOOP && (2 * NX + NU + NP <= kWave);
+    const double* m_src = nullptr;
+    int m_stride = 0, m_dst = 0;
+    bool m_on = false;
+    if (MERGED) {
+        int l = lane;
+        if (l < NX) { m_src = xs + l; m_stride = NX; m_dst = L::RO_X + l; m_on = true; }
+        else if ((l -= NX) < NU) { m_src = us + l; m_stride = NU; m_dst = L::RO_U + l; m_on = true; }
+        else if ((l -= NU) < NP) { m_src = P + l; m_stride = NP; m_dst = L::RO_P + l; m_on = true; }
+        else if ((l -= NP) < NX) { m_src = dft + l; m_stride = NX; m_dst = L::RO_D + l; m_on = true; }
+    }
+    double r_x = 0, r_u = 0, r_p = 0, r_d = 0, r_m = 0, r_g[RG];
     auto fetch = [&](int k) {
-        if (lane < NU) r_u = us[k * NU + lane];
-        if (lane < NP) r_p = P[k * NP + lane];
+        if (MERGED) {
+            if (m_on) r_m = m_src[size_t(k) * m_stride];
+        } else {
+            if (lane < NU) r_u = us[k * NU + lane];
+            if (lane < NP) r_p = P[k * NP + lane];
+            if (!OPEN_LOOP && lane < NX) { r_x = xs[k * NX + lane]; r_d = dft[k * NX + lane]; }
+        }
         if (!OPEN_LOOP) {
-            if (lane < NX) { r_x = xs[k * NX + lane]; r_d = dft[k * NX + lane]; }
             const double* gk = gains + size_t(k) * NG;
 #pragma unroll
             for (int t = 0; t < RG; ++t) r_g[t] = (lane + t * kWave < NG) ? gk[lane + t * kWave] : 0.0;
@@ -546,10 +564,14 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
     double J = 0.0;
     const double oma = 1.0 - alpha;
     for (int k = 0; k < N; ++k) {
-        if (lane < NU) ro[L::RO_U + lane] = r_u;
-        if (lane < NP) ro[L::RO_P + lane] = r_p;
+        if (MERGED) {
+            if (m_on) ro[m_dst] = r_m;
+        } else {
+            if (lane < NU) ro[L::RO_U + lane] = r_u;
+            if (lane < NP) ro[L::RO_P + lane] = r_p;
+            if (!OPEN_LOOP && lane < NX) { ro[L::RO_X + lane] = r_x; ro[L::RO_D + lane] = r_d; }
+        }
         if (!OPEN_LOOP) {
-            if (lane < NX) { ro[L::RO_X + lane] = r_x; ro[L::RO_D + lane] = r_d; }
 #pragma unroll
             for (int t = 0; t < RG; ++t)
                 if (lane + t * kWave < NG) ro[L::RO_G + lane + t * kWave] = r_g[t];
