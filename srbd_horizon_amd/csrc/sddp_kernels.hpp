@@ -61,6 +61,16 @@ struct SolveArgs {
     double mu;          // backward test kernel only
 };
 
+// Hand-off between phases of a ONE-WAVEFRONT workgroup.  LDS (and global) accesses of one wave are performed in issue order, so a
+// later ds_read of any lane sees an earlier ds_write of any lane without waiting; what must not happen is the COMPILER moving
+// accesses across the hand-off.  A wavefront-scope fence does exactly that and costs no instruction, where __syncthreads()
+// costs an s_waitcnt lgkmcnt(0) that also drains loads still in flight.  (The 4-wave kernels use real barriers.)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
@@ -188,9 +198,9 @@ __device__ void sweep_tables(const DevConsts& c, double* s, int lane) {
     using L = Lds<M>;
     constexpr int NX = M::NX, NZ = M::NZ, NE = M::NE;
     for (int e = lane; e < L::TOTAL; e += kWave) s[e] = 0.0;
-    __syncthreads();
+    wave_sync();
     for (int e = lane; e < M::NREC; e += kWave) s[L::REC + e] = 0.0;         // zero record -> constant part of F
-    __syncthreads();
+    wave_sync();
     for (int e = lane; e < NZ * NX; e += kWave) {
         const int j = e / NX, i = e % NX;
         s[L::FT + j * L::NIP + i] = M::F_entry(c, s + L::REC, i, j);
@@ -222,7 +232,7 @@ __device__ void sweep_tables(const DevConsts& c, double* s, int lane) {
         while ((ba + 1) * (ba + 2) / 2 <= t) ++ba;
         ki[2 * L::NZP + L::NTRIQ + t] = (ba << 8) | (t - ba * (ba + 1) / 2);
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -258,7 +268,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         const double* rN = rec + size_t(N) * NREC;
         if (lane < NXP) s[L::VX + lane] = lane < NX ? rN[M::REC_G + lane] : 0.0;
         if (lane < NP) s[L::PK + lane] = P[N * NP + lane];
-        __syncthreads();
+        wave_sync();
         for (int e = lane; e < NXP * NXP; e += kWave) {
             const int a = e / NXP, b = e % NXP;
             double v = 0.0;
@@ -274,7 +284,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             const int j = e / NE, m = e % NE;
             s[L::WT + j * NIP + NX + m] = s[L::LAM + m] * s[L::FT + j * NIP + NX + m];
         }
-        __syncthreads();
+        wave_sync();
     }
     // ---- prefetch knot N-1
     double r_rec[RREC], r_p = 0.0, r_d = 0.0;
@@ -299,7 +309,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             if (lane < NP) r_p = P[(k - 1) * NP + lane];
             if (lane < NX) r_d = dft[(k - 1) * NX + lane];
         }
-        __syncthreads();
+        wave_sync();
         SDDP_TICK(1)
         const double state = k >= 1 ? 1.0 : 0.0;
         // ---- expand: variable entries of F~^T; v' = Vx + Vxx d ; gap terms
@@ -317,7 +327,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             G1 = fma(d, vx, G1);                 // per-lane partial sums, reduced once after the sweep
             G2 = fma(0.5 * d, acc, G2);
         }
-        __syncthreads();
+        wave_sync();
         SDDP_TICK(2)
         // ---- WT = (V~ F~)^T : 2 (l) x 4 (j) register blocks, inner product over the NX dynamics rows
         for (int blk = lane; blk < (NXP / 2) * (NZP / 4); blk += kWave) {
@@ -347,13 +357,13 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             }
         }
         if (k == 0) {   // node 0 carries no state residuals: rescale the extra rows with the stage-only weights
-            __syncthreads();
+            wave_sync();
             for (int e = lane; e < NZ * NE; e += kWave) {
                 const int j = e / NE, m = e % NE;
                 s[L::WT + j * NIP + NX + m] = s[L::LG + m] * s[L::FT + j * NIP + NX + m];
             }
         }
-        __syncthreads();
+        wave_sync();
         SDDP_TICK(3)
         // ---- Q = diag(D) + F~^T (V~ F~): lower-triangle 2x2 blocks, mirrored ; q = g + F^T v'
 #pragma unroll
@@ -401,10 +411,10 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
                 s[L::QV + j] = acc;
             }
         }
-        __syncthreads();
+        wave_sync();
         if (theta != 0.0) {   // exact second-order torque term (wave-uniform switch)
             M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, NZP, theta, lane, kWave);
-            __syncthreads();
+            wave_sync();
         }
         SDDP_TICK(4)
         // ---- [k K] = -Quu^-1 [Qu Qux]: Gauss-Jordan, lane j owns column j of [Quu+mu I | Qu | Qux]
@@ -455,7 +465,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             for (int i = 0; i < NU; ++i) dv += -a[i] * qu_save[i];
         }
         dV1 += readlane_d(dv, NU);
-        __syncthreads();
+        wave_sync();
         SDDP_TICK(5)
         if (!ok) return false;
         // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + Qux^T K.  Qux^T K = -Qux^T (Quu + mu I)^-1 Qux is symmetric, so only the lower
@@ -499,7 +509,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
                 *reinterpret_cast<double2_t*>(s + L::VXX + (c0 + 1) * NXP + a0) = m1;
             }
         }
-        __syncthreads();
+        wave_sync();
         SDDP_TICK(6)
     }
     G1 = wave_sum(G1);
@@ -527,10 +537,10 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
     if (store_lane < 0 && storing) { xn += size_t(lane) * (N + 1) * NX; un += size_t(lane) * N * NU; }
     double x[NX];
     if (lane < NX) ro[L::RO_X + lane] = x0[lane];
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = ro[L::RO_X + i];
-    __syncthreads();
+    wave_sync();
     // knot operands x_k | u_k | p_k | d_k: when they fit one wave (2 NX + NU + NP <= 64) every lane owns ONE word of the knot:
     // its source pointer / knot stride / LDS slot are fixed for the whole pass, so a knot costs one load and one LDS store
     // (plus the gain rows) instead of four masked pairs
@@ -577,7 +587,7 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
                 if (lane + t * kWave < NG) ro[L::RO_G + lane + t * kWave] = r_g[t];
         }
         if (k + 1 < N) fetch(k + 1);
-        __syncthreads();
+        wave_sync();
         double u[NU];
         if (OPEN_LOOP) {
 #pragma unroll
@@ -605,16 +615,16 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
 #pragma unroll
             for (int i = 0; i < NX; ++i) x[i] -= oma * ro[L::RO_D + i];
         }
-        __syncthreads();
+        wave_sync();
     }
     if (lane < NP) ro[L::RO_P + lane] = P[N * NP + lane];
-    __syncthreads();
+    wave_sync();
     J += M::term_cost(c, x, ro + L::RO_P);
     if (storing) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[N * NX + i] = x[i];
     }
-    __syncthreads();
+    wave_sync();
     return J;
 }
 
@@ -648,15 +658,15 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
     // ---- starting point
     if (o.initial_rollout) {
         J = rollout<M, true>(A.c, N, x0, P, xs, us, dft, gains, xc, uc, 0.0, 0, lane, s);
-        __syncthreads();
+        wave_sync();
         for (int e = lane; e < (N + 1) * NX; e += kWave) xs[e] = xc[e];
         for (int e = lane; e < N * NX; e += kWave) dft[e] = 0.0;
-        __syncthreads();
+        wave_sync();
     } else {
         if (lane < NX) xs[lane] = x0[lane];
-        __syncthreads();
+        wave_sync();
         phase_defects<M>(A.c, N, xs, us, P, dft, lane, J, gap);
-        __syncthreads();
+        wave_sync();
     }
     double mu = o.mu0, rho = 0.0, alpha = 0.0, expected = 0.0, theta = 0.0;
     int iters = 0, converged = 0, status = 1, rollouts = 0, win = 0;
@@ -665,7 +675,7 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
         while (iters < o.max_iters) {
             SDDP_TICK(9)
             phase_derivs<M>(A.c, N, xs, us, P, rec, lane);
-            __syncthreads();
+            wave_sync();
             SDDP_TICK(0)
             double dV1, G1, G2, qu_inf, a_win = 0.0, J_win = 0.0;
             bool ok = true, stop = false, accepted = false;
@@ -706,7 +716,7 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
                         a_win = __shfl(a, win, kWave);
                         J_win = __shfl(Jl, win, kWave);
                         if (win >= kSlots) {   // the winner is not one of the kept candidates: roll it again into slot 0
-                            __syncthreads();
+                            wave_sync();
                             rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xw, uw, a, win, lane, s);
                             ++rollouts;
                             win = 0;
@@ -726,7 +736,7 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
             theta = (o.second_order && alpha == o.alpha_0) ? 1.0 : 0.0;
             const double dJ = J - J_win;
             J = J_win;
-            __syncthreads();
+            wave_sync();
             xs = xc + (size_t(wr) * kSlots + win) * XS;          // the accepted candidate becomes the iterate; next pass writes
             us = uc + (size_t(wr) * kSlots + win) * US;          // the other set
             wr ^= 1;
@@ -735,11 +745,11 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
             gap *= oma;
             ++iters;
             if (mu > o.mu0) mu = fmax(o.mu0, mu * 0.1);
-            __syncthreads();
+            wave_sync();
             if (fabs(dJ) < o.cost_reduction_ths && gap <= o.gap_tol) { converged = 1; status = 0; break; }
         }
     // ---- results live in A.xs/A.us: copy back if the iterate ended in the candidate buffers
-    __syncthreads();
+    wave_sync();
     double* xs0 = A.xs + size_t(b) * (N + 1) * NX;
     if (xs != xs0) {
         double* us0 = A.us + size_t(b) * N * NU;
@@ -805,7 +815,7 @@ __global__ __launch_bounds__(kWave) void eval_knots_kernel(DevConsts c, int N, i
 #pragma unroll
         for (int i = 0; i < NX; ++i) f_out[t * NX + i] = xn[i];
     }
-    __syncthreads();
+    wave_sync();
     for (int e = lane; e < NX * NZ; e += kWave) F_out[size_t(t) * NX * NZ + e] = k < N ? M::F_entry(c, r, e / NZ, e % NZ) : 0.0;
     for (int e = lane; e < NZ * NZ; e += kWave) {
         const int i = e / NZ, j = e % NZ;
@@ -831,7 +841,7 @@ __global__ __launch_bounds__(kWave) void backward_kernel(SolveArgs A) {
     sweep_tables<M>(A.c, s, lane);
     phase_defects<M>(A.c, N, xs, us, P, dft, lane, J, gap);
     phase_derivs<M>(A.c, N, xs, us, P, rec, lane);
-    __syncthreads();
+    wave_sync();
     double dV1, G1, G2, qu_inf;
     SDDP_T_DECL
     const bool ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, A.mu, A.alpha, s, lane, dV1, G1, G2, qu_inf SDDP_T_PASS);
