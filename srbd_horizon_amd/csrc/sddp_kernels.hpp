@@ -458,24 +458,21 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
                 gk[i * gstride] = -a[i];
             }
         }
-        // dV1 += kff . Qu   (dV2 = 1/2 kff^T Quu kff = -1/2 dV1 exactly, not accumulated separately)
-        double dv = 0.0;
-        if (lane == NU) {
+        // kff broadcast from lane NU; then ONE dot product per lane with the column it loaded gives both
+        //   lane NU:        kff . Qu           -> dV1 (dV2 = 1/2 kff^T Quu kff = -1/2 dV1 exactly, not accumulated separately)
+        //   lane NU+1+c:    (Qux^T kff)[c]     -> Vx[c] = Qx[c] + Qux^T kff
+        {
+            double dot = 0.0;
 #pragma unroll
-            for (int i = 0; i < NU; ++i) dv += -a[i] * qu_save[i];
+            for (int i = 0; i < NU; ++i) dot = fma(readlane_d(-a[i], NU), qu_save[i], dot);
+            dV1 += readlane_d(dot, NU);
+            if (lane > NU && lane < NCOL) s[L::VX + lane - NU - 1] = s[L::QV + lane - NU - 1] + dot;
         }
-        dV1 += readlane_d(dv, NU);
         wave_sync();
         SDDP_TICK(5)
         if (!ok) return false;
         // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + Qux^T K.  Qux^T K = -Qux^T (Quu + mu I)^-1 Qux is symmetric, so only the lower
         //      triangle is formed (2x2 blocks, one product per element) and mirrored; diagonal blocks are symmetrised
-        if (lane < NX) {
-            double acc = s[L::QV + lane];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) acc += s[L::Q + lane * NZP + NX + i] * s[L::KF + i];
-            s[L::VX + lane] = acc;
-        }
 #pragma unroll
         for (int q = 0; q < PV; ++q) {
             if (lane + q * kWave >= L::NTRIV) break;
