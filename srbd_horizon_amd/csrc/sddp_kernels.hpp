@@ -83,13 +83,6 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     hi = __builtin_amdgcn_readlane(hi, l);
     return __hiloint2double(hi, lo);
 }
-// 1/x to fp64 accuracy: hardware estimate + 2 Newton steps (pivots are checked > 0 and finite before use)
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, kWave));

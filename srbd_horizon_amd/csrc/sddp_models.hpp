@@ -102,12 +102,20 @@ __device__ __forceinline__ void matmul3(const double* A, const double* B, double
 #pragma unroll
         for (int j = 0; j < 3; ++j) o[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
+// 1/x to fp64 accuracy: hardware estimate + 2 Newton steps, 5 instructions instead of the ~30 of an IEEE division.
+// x = 0 or non-finite gives a non-finite result, which the callers treat like the division's (pivot checks, cost checks).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
 __device__ __forceinline__ void inv3(const double* M, double* o) {
     const double c00 = M[4] * M[8] - M[5] * M[7];
     const double c01 = M[5] * M[6] - M[3] * M[8];
     const double c02 = M[3] * M[7] - M[4] * M[6];
     const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
-    const double id = 1.0 / det;
+    const double id = fast_rcp(det);
     o[0] = c00 * id;
     o[1] = (M[2] * M[7] - M[1] * M[8]) * id;
     o[2] = (M[1] * M[5] - M[2] * M[4]) * id;
