@@ -236,7 +236,8 @@ __device__ void sweep_tables(const DevConsts& c, double* s, int lane) {
 template <class M>
 __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restrict__ P, const double* __restrict__ dft,
                                const double* __restrict__ rec, double* __restrict__ gains, double mu, double theta, double* s,
-                               int lane, double& dV1, double& G1, double& G2, double& qu_inf SDDP_T_ARG) {
+                               int lane, double& dV1, double& G1, double& G2, double& qu_inf, bool has_gap SDDP_T_ARG) {
+    // has_gap = false: all defects are zero (every iteration after the first full step): v' = Vx, no Vxx d product
     using L = Lds<M>;
     constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NREC = M::NREC, NP = M::NP;
     constexpr int NXP = L::NXP, NIP = L::NIP, NZP = L::NZP, NUP = L::NUP;
@@ -309,10 +310,12 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         M::expand_var(c, s + L::REC, s + L::FT, NIP, lane, kWave, s + L::WT, s + L::LAM);
         if (lane < NX) {
             double acc = 0.0;
+            if (has_gap) {
 #pragma unroll
-            for (int m = 0; m < NXP; m += 2) {
-                const double2_t v = lds2(s + L::VXX + lane * NXP + m), d = lds2(s + L::DK + m);
-                acc = fma(v.y, d.y, fma(v.x, d.x, acc));
+                for (int m = 0; m < NXP; m += 2) {
+                    const double2_t v = lds2(s + L::VXX + lane * NXP + m), d = lds2(s + L::DK + m);
+                    acc = fma(v.y, d.y, fma(v.x, d.x, acc));
+                }
             }
             const double d = s[L::DK + lane], vx = s[L::VX + lane];
             s[L::VP + lane] = vx + acc;
@@ -671,7 +674,7 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
             bool ok = true, stop = false, accepted = false;
             do {   // at most twice: a failed sweep / line search with the second-order term is redone without it
                 while (true) {
-                    ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, mu, theta, s, lane, dV1, G1, G2, qu_inf SDDP_T_PASS);
+                    ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, mu, theta, s, lane, dV1, G1, G2, qu_inf, gap > 0.0 SDDP_T_PASS);
                     if (ok) break;
                     if (theta != 0.0) { theta = 0.0; continue; }
                     mu = fmax(mu, 0.0) * 10.0 + o.mu_min;
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(kWave) void backward_kernel(SolveArgs A) {
     wave_sync();
     double dV1, G1, G2, qu_inf;
     SDDP_T_DECL
-    const bool ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, A.mu, A.alpha, s, lane, dV1, G1, G2, qu_inf SDDP_T_PASS);
+    const bool ok = backward_sweep<M>(A.c, N, P, dft, rec, gains, A.mu, A.alpha, s, lane, dV1, G1, G2, qu_inf, true SDDP_T_PASS);
     if (lane == 0) {
         double* sc = A.scal + size_t(b) * kScal;
         sc[0] = dV1; sc[1] = -0.5 * dV1; sc[2] = G1; sc[3] = G2; sc[4] = ok ? 1.0 : 0.0; sc[5] = A.mu; sc[6] = qu_inf; sc[7] = J;
