@@ -280,29 +280,35 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         }
         wave_sync();
     }
-    // ---- prefetch knot N-1
+    // ---- knot operands record | parameters | defect.  The last record word group and the parameters share one load: lanes past
+    //      the record's tail take the parameters (fixed per-lane source / knot stride / LDS slot).  The defect is staged only
+    //      while there is one (has_gap); otherwise its slot stays zero.
+    constexpr int RTAIL = NREC - (RREC - 1) * kWave;                  // record words in the last group
+    constexpr bool MERGE_P = RTAIL + NP <= kWave;
+    const bool tail_rec = lane < RTAIL, tail_par = MERGE_P && lane >= RTAIL && lane < RTAIL + NP;
+    const double* t_src = tail_rec ? rec + (RREC - 1) * kWave + lane : P + (lane - RTAIL);
+    const int t_stride = tail_rec ? NREC : NP;
+    const int t_dst = tail_rec ? L::REC + (RREC - 1) * kWave + lane : L::PK + (lane - RTAIL);
+    const bool t_on = tail_rec || tail_par;
     double r_rec[RREC], r_p = 0.0, r_d = 0.0;
-    {
-        const double* rk = rec + size_t(N - 1) * NREC;
+    auto fetch = [&](int k) {
+        const double* rk = rec + size_t(k) * NREC;
 #pragma unroll
-        for (int t = 0; t < RREC; ++t) r_rec[t] = (lane + t * kWave < NREC) ? rk[lane + t * kWave] : 0.0;
-        if (lane < NP) r_p = P[(N - 1) * NP + lane];
-        if (lane < NX) r_d = dft[(N - 1) * NX + lane];
-    }
+        for (int t = 0; t + 1 < RREC; ++t) r_rec[t] = rk[lane + t * kWave];
+        if (t_on) r_rec[RREC - 1] = t_src[size_t(k) * t_stride];
+        if (!MERGE_P && lane < NP) r_p = P[k * NP + lane];
+        if (has_gap && lane < NX) r_d = dft[k * NX + lane];
+    };
+    if (lane < NXP) s[L::DK + lane] = 0.0;
+    fetch(N - 1);
     for (int k = N - 1; k >= 0; --k) {
         // ---- stage this knot from the prefetch registers; start the next knot's loads
 #pragma unroll
-        for (int t = 0; t < RREC; ++t)
-            if (lane + t * kWave < NREC) s[L::REC + lane + t * kWave] = r_rec[t];
-        if (lane < NP) s[L::PK + lane] = r_p;
-        if (lane < NXP) s[L::DK + lane] = lane < NX ? r_d : 0.0;
-        if (k > 0) {
-            const double* rk = rec + size_t(k - 1) * NREC;
-#pragma unroll
-            for (int t = 0; t < RREC; ++t) r_rec[t] = (lane + t * kWave < NREC) ? rk[lane + t * kWave] : 0.0;
-            if (lane < NP) r_p = P[(k - 1) * NP + lane];
-            if (lane < NX) r_d = dft[(k - 1) * NX + lane];
-        }
+        for (int t = 0; t + 1 < RREC; ++t) s[L::REC + lane + t * kWave] = r_rec[t];
+        if (t_on) s[t_dst] = r_rec[RREC - 1];
+        if (!MERGE_P && lane < NP) s[L::PK + lane] = r_p;
+        if (has_gap && lane < NX) s[L::DK + lane] = r_d;
+        if (k > 0) fetch(k - 1);
         wave_sync();
         SDDP_TICK(1)
         const double state = k >= 1 ? 1.0 : 0.0;
