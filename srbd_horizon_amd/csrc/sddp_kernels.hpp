@@ -526,7 +526,8 @@ template <class M, bool OPEN_LOOP>
 __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
                           const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
                           const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
-                          double alpha, int store_lane, int lane, double* s) {
+                          double alpha, int store_lane, int lane, double* s, bool has_gap = true) {
+    // has_gap = false: all defects are zero, the (1 - alpha) d correction is skipped.
     // store_lane >= 0: that lane writes its trajectory to xn / un.  store_lane < 0: lanes 0 .. kSlots-1 each write theirs to
     // slot `lane` of xn / un (slot strides (N+1) NX and N NU): same instruction count, no second pass to fetch the winner.
     using L = Lds<M>;
@@ -610,7 +611,7 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
             for (int i = 0; i < NU; ++i) un[k * NU + i] = u[i];
         }
         J += M::step(c, x, u, ro + L::RO_P, k, x);               // in place: every component is read before it is written
-        if (!OPEN_LOOP) {
+        if (!OPEN_LOOP && has_gap) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) x[i] -= oma * ro[L::RO_D + i];
         }
@@ -703,7 +704,7 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
                     SDDP_TICK(9)
                     double* xw = xc + size_t(wr) * kSlots * XS;
                     double* uw = uc + size_t(wr) * kSlots * US;
-                    double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xw, uw, a, -1, lane, s);
+                    double Jl = rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xw, uw, a, -1, lane, s, gap > 0.0);
                     SDDP_TICK(8)
                     ++rollouts;
                     const double pred = a * A1 + a * a * B2 - a * rho * gap;
@@ -716,7 +717,7 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
                         J_win = __shfl(Jl, win, kWave);
                         if (win >= kSlots) {   // the winner is not one of the kept candidates: roll it again into slot 0
                             wave_sync();
-                            rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xw, uw, a, win, lane, s);
+                            rollout<M, false>(A.c, N, x0, P, xs, us, dft, gains, xw, uw, a, win, lane, s, gap > 0.0);
                             ++rollouts;
                             win = 0;
                         }
@@ -740,7 +741,9 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
             us = uc + (size_t(wr) * kSlots + win) * US;          // the other set
             wr ^= 1;
             const double oma = 1.0 - alpha;
-            for (int e = lane; e < N * NX; e += kWave) dft[e] *= oma;
+            if (gap > 0.0) {
+                for (int e = lane; e < N * NX; e += kWave) dft[e] *= oma;     // a full step writes exact zeros
+            }
             gap *= oma;
             ++iters;
             if (mu > o.mu0) mu = fmax(o.mu0, mu * 0.1);
