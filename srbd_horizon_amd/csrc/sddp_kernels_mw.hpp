@@ -182,6 +182,10 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         if (a == b) v += s[L::DS + a] + M::dparam(c, s + L::PK, ki[a], ki[SQ + a], 1.0, 0.0);
         s[L::VXX + a * SV + b] = v;
     }
+    // the block this thread owns in the Q / Vxx phases never changes: read the LUTs once per sweep
+    const int code_q = tid < L::NTRIQ ? ki[2 * SQ + tid] : 0;
+    const int code_v = tid < L::NTRIV ? ki[2 * SQ + L::NTRIQ + tid] : 0;
+    static_assert(L::NTRIQ <= kThreadsMW && L::NTRIV <= kThreadsMW, "one block per thread");
     double r_stage[RS];
 #pragma unroll
     for (int t = 0; t < RS; ++t) r_stage[t] = stage_word(N - 1, tid + t * kThreadsMW);
@@ -238,8 +242,8 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         __syncthreads();
         SDDP_TICK(3)
         // ---- Q = diag(D) + F~^T (V~ F~): 3x3 lower-triangle blocks, mirrored ; q = g + F^T v'
-        for (int t = tid; t < L::NTRIQ; t += kThreadsMW) {
-            const int code = ki[2 * SQ + t];
+        if (tid < L::NTRIQ) {
+            const int code = code_q;
             const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
             double acc[3][3] = {};
             dot_block<3, 3, SI>(s + L::FT + a0 * SI, SI, s + L::WT + b0 * SI, SI, acc);
@@ -284,15 +288,16 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         // ---- [k K] = -Quu^-1 [Qu Qux]: block Gauss-Jordan, lane j = column j of [Quu+mu I | Qu | Qux], wave w = rows w RPW ..
         {
             double a[RPW], qu_save[RPW];
+            // column of Q this lane reads (any valid one for lane NU, which takes q instead; lanes >= NCOL are zeroed): branch-free
+            const int qcol = lane < NU ? NX + lane : (lane > NU && lane < NCOL ? lane - NU - 1 : 0);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int i = wave * RPW + r;
-                double v = 0.0;
-                if (i < NU) {
-                    if (lane < NU) v = s[L::Q + (NX + i) * SQ + NX + lane] + (i == lane ? mu : 0.0);
-                    else if (lane == NU) v = s[L::QV + NX + i];
-                    else if (lane < NCOL) v = s[L::Q + (NX + i) * SQ + (lane - NU - 1)];
-                }
+                const int i = wave * RPW + r, ic = i < NU ? i : NU - 1;
+                double v = s[L::Q + (NX + ic) * SQ + qcol];
+                const double qv = s[L::QV + NX + ic];
+                v = lane == NU ? qv : v;
+                v += (i == lane) ? mu : 0.0;
+                v = (i < NU && lane < NCOL) ? v : 0.0;
                 a[r] = v;
                 qu_save[r] = v;
                 qu_acc = fmax(qu_acc, fabs(v));          // only lane NU's value is used
@@ -338,12 +343,17 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             }
             // a = Quu^-1 * column ; publish kff and K^T (negated) ; dV1 += kff . Qu
             double dv = 0.0;
+            // also the gains to HBM/L2 straight from the registers: kff (NU) then K (NU x NX) row-major; row i of K is one
+            // contiguous store of the NX column lanes
+            double* dst = lane == NU ? s + L::KF : s + L::KT + (lane - NU - 1) * SK;
+            double* gk = gains + size_t(k) * (NU * (NX + 1)) + (lane == NU ? 0 : NU + (lane - NU - 1));
+            const int gstride = lane == NU ? 1 : NX;
+            const bool pub = lane >= NU && lane < NCOL;
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int i = wave * RPW + r;
                 if (i < NU) {
-                    if (lane == NU) s[L::KF + i] = -a[r];
-                    if (lane > NU && lane < NCOL) s[L::KT + (lane - NU - 1) * SK + i] = -a[r];
+                    if (pub) { dst[i] = -a[r]; gk[i * gstride] = -a[r]; }
                     dv += -a[r] * qu_save[r];
                 }
             }
@@ -357,8 +367,8 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             for (int i = 0; i < NU; ++i) acc += s[L::Q + lane * SQ + NX + i] * s[L::KF + i];
             s[L::VX + lane] = acc;
         }
-        for (int t = tid; t < L::NTRIV; t += kThreadsMW) {
-            const int code = ki[2 * SQ + L::NTRIQ + t];
+        if (tid < L::NTRIV) {
+            const int code = code_v;
             const int a0 = 2 * (code >> 8), c0 = 2 * (code & 255);
             const int a1 = a0 + 1 < NX ? a0 + 1 : a0, c1 = c0 + 1 < NX ? c0 + 1 : c0;    // odd NX: clamp, not stored
             double v00 = 0, v01 = 0, v10 = 0, v11 = 0;
@@ -386,16 +396,6 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 if (hc) s[L::VXX + (c0 + 1) * SV + a0] = v01;
                 if (ha) s[L::VXX + c0 * SV + a0 + 1] = v10;
                 if (ha && hc) s[L::VXX + (c0 + 1) * SV + a0 + 1] = v11;
-            }
-        }
-        // ---- gains to HBM/L2: kff (NU) then K (NU x NX) row-major, coalesced
-        {
-            double* gk = gains + size_t(k) * (NU * (NX + 1));
-            for (int e = tid; e < NU * (NX + 1); e += kThreadsMW) {
-                double v;
-                if (e < NU) v = s[L::KF + e];
-                else { const int i = (e - NU) / NX, j = (e - NU) % NX; v = s[L::KT + j * SK + i]; }
-                gk[e] = v;
             }
         }
         __syncthreads();
