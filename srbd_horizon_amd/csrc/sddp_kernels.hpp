@@ -331,22 +331,29 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         }
         wave_sync();
         SDDP_TICK(2)
-        // ---- WT = (V~ F~)^T : 2 (l) x 4 (j) register blocks, inner product over the NX dynamics rows
-        for (int blk = lane; blk < (NXP / 2) * (NZP / 4); blk += kWave) {
-            const int l0 = 2 * (blk % (NXP / 2)), j0 = 4 * (blk / (NXP / 2));
-            double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+        // ---- WT = (V~ F~)^T : 2 (l) x JB (j) register blocks, inner product over the NX dynamics rows.  JB = 3 when that still
+        //      fits one pass of the wave (more lanes, a shorter chain per lane), else 4.  A block may reach one row past the
+        //      F~^T tile (the row after it is the first row of WT: finite, never stored).
+        constexpr int JB = ((NXP / 2) * ((NZP + 2) / 3) <= kWave) ? 3 : 4;
+        constexpr int NJB = (NZP + JB - 1) / JB;
+        for (int blk = lane; blk < (NXP / 2) * NJB; blk += kWave) {
+            const int l0 = 2 * (blk % (NXP / 2)), j0 = JB * (blk / (NXP / 2));
+            double a0[JB], a1[JB];
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) a0[jj] = a1[jj] = 0.0;
 #pragma unroll
             for (int m = 0; m < NXP; m += 2) {
                 const double2_t v0 = lds2(s + L::VXX + l0 * NXP + m), v1 = lds2(s + L::VXX + (l0 + 1) * NXP + m);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
+                for (int jj = 0; jj < JB; ++jj) {
                     const double2_t f = lds2(s + L::FT + (j0 + jj) * NIP + m);
                     a0[jj] = fma(v0.y, f.y, fma(v0.x, f.x, a0[jj]));
                     a1[jj] = fma(v1.y, f.y, fma(v1.x, f.x, a1[jj]));
                 }
             }
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
+            for (int jj = 0; jj < JB; ++jj) {
+                if (j0 + jj >= NZP) continue;
                 if (l0 + 1 < NX) {
                     double2_t w;
                     w.x = a0[jj];
