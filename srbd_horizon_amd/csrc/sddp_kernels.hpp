@@ -124,7 +124,8 @@ struct Lds {
     static constexpr int LAM = LG + ((NE + 1) & ~1);   // LS + LG: extra-row weights of a stage node k >= 1
     static constexpr int KI = LAM + ((NE + 1) & ~1);   // ints: dkind[NZP], dci[NZP], tri LUT
     static constexpr int NBQ = NZP / 2, NTRIQ = NBQ * (NBQ + 1) / 2;
-    static constexpr int NBV = NXP / 2, NTRIV = NBV * (NBV + 1) / 2;
+    static constexpr int ntriv(int nx) { int n = 0; for (int a = 0; a < nx; ++a) n += a / 2 + 1; return n; }
+    static constexpr int NTRIV = ntriv(NX);        // Vxx update: 1 x 2 blocks (row a, column pair 2bp, 2bp+1 with 2bp <= a)
     static constexpr int KI_INTS = 2 * NZP + NTRIQ + NTRIV;
     static constexpr int RO = KI + (KI_INTS + 1) / 2;  // rollout staging: xs | us | p | gains | dft of one knot
     static constexpr int RO_X = 0, RO_U = NXP, RO_P = RO_U + NUP, RO_G = RO_P + NPP, RO_D = RO_G + ((NU * (NX + 1) + 1) & ~1);
@@ -220,10 +221,10 @@ __device__ void sweep_tables(const DevConsts& c, double* s, int lane) {
         while ((ba + 1) * (ba + 2) / 2 <= t) ++ba;
         ki[2 * L::NZP + t] = (ba << 8) | (t - ba * (ba + 1) / 2);
     }
-    for (int t = lane; t < L::NTRIV; t += kWave) {
-        int ba = 0;
-        while ((ba + 1) * (ba + 2) / 2 <= t) ++ba;
-        ki[2 * L::NZP + L::NTRIQ + t] = (ba << 8) | (t - ba * (ba + 1) / 2);
+    for (int t = lane; t < L::NTRIV; t += kWave) {          // t -> (row a << 8) | column pair bp
+        int a = 0, first = 0;
+        while (first + a / 2 + 1 <= t) { first += a / 2 + 1; ++a; }
+        ki[2 * L::NZP + L::NTRIQ + t] = (a << 8) | (t - first);
     }
     wave_sync();
 }
@@ -480,39 +481,27 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         wave_sync();
         SDDP_TICK(5)
         if (!ok) return false;
-        // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + Qux^T K.  Qux^T K = -Qux^T (Quu + mu I)^-1 Qux is symmetric, so only the lower
-        //      triangle is formed (2x2 blocks, one product per element) and mirrored; diagonal blocks are symmetrised
+        // ---- Vxx = Qxx + Qux^T K.  Qux^T K = -Qux^T (Quu + mu I)^-1 Qux is symmetric, so only the lower triangle is formed (one
+        //      product per element, 1 x 2 blocks: 49 lanes with a 12-FMA chain each) and mirrored
 #pragma unroll
         for (int q = 0; q < PV; ++q) {
             if (lane + q * kWave >= L::NTRIV) break;
             const int code = codev[q];
-            const int a0 = 2 * (code >> 8), c0 = 2 * (code & 255);
-            double v00 = 0, v01 = 0, v10 = 0, v11 = 0;
+            const int a0 = code >> 8, c0 = 2 * (code & 255);        // row a0, columns c0, c0 + 1 (c0 <= a0)
+            const bool two = c0 + 1 <= a0;                          // the second column is in the lower triangle too
+            const int c1 = two ? c0 + 1 : c0;
+            double v0 = s[L::Q + a0 * NZP + c0], v1 = s[L::Q + a0 * NZP + c1];
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                const double qa = s[L::Q + a0 * NZP + NX + i], qb = s[L::Q + (a0 + 1) * NZP + NX + i];
-                const double kc = s[L::KT + c0 * NUP + i], kd = s[L::KT + (c0 + 1) * NUP + i];
-                v00 = fma(qa, kc, v00);
-                v01 = fma(qa, kd, v01);
-                v10 = fma(qb, kc, v10);
-                v11 = fma(qb, kd, v11);
+                const double qa = s[L::Q + a0 * NZP + NX + i];
+                v0 = fma(qa, s[L::KT + c0 * NUP + i], v0);
+                v1 = fma(qa, s[L::KT + c1 * NUP + i], v1);
             }
-            v00 += s[L::Q + a0 * NZP + c0];
-            v01 += s[L::Q + a0 * NZP + c0 + 1];
-            v10 += s[L::Q + (a0 + 1) * NZP + c0];
-            v11 += s[L::Q + (a0 + 1) * NZP + c0 + 1];
-            if (a0 + 1 >= NX) { v10 = 0.0; v11 = 0.0; }
-            if (c0 + 1 >= NX) { v01 = 0.0; v11 = 0.0; }
-            if (a0 == c0) { const double off = 0.5 * (v01 + v10); v01 = v10 = off; }
-            double2_t r0, r1;
-            r0.x = v00; r0.y = v01; r1.x = v10; r1.y = v11;
-            *reinterpret_cast<double2_t*>(s + L::VXX + a0 * NXP + c0) = r0;
-            *reinterpret_cast<double2_t*>(s + L::VXX + (a0 + 1) * NXP + c0) = r1;
-            if (a0 != c0) {
-                double2_t m0, m1;
-                m0.x = v00; m0.y = v10; m1.x = v01; m1.y = v11;
-                *reinterpret_cast<double2_t*>(s + L::VXX + c0 * NXP + a0) = m0;
-                *reinterpret_cast<double2_t*>(s + L::VXX + (c0 + 1) * NXP + a0) = m1;
+            s[L::VXX + a0 * NXP + c0] = v0;
+            if (c0 != a0) s[L::VXX + c0 * NXP + a0] = v0;
+            if (two) {
+                s[L::VXX + a0 * NXP + c1] = v1;
+                if (c1 != a0) s[L::VXX + c1 * NXP + a0] = v1;
             }
         }
         wave_sync();
