@@ -97,9 +97,9 @@ __device__ __forceinline__ double wave_max(double v) {
 //   Q   [NZP][NZP]  diag(D) + F~^T (V~ F~)   (symmetric, both triangles written)
 template <class M>
 struct Lds {
-    static constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NI = NX + NE;
+    static constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NEV = M::NEV, NI = NX + NEV;   // product rows only
     static constexpr int NXP = (NX + 1) & ~1;
-    static constexpr int NIP = (NI + 1) & ~1;
+    static constexpr int NIP = (((NI + 1) & ~1) % 4 == 0) ? ((NI + 1) & ~1) + 2 : ((NI + 1) & ~1);   // even, == 2 (mod 4): rows on distinct 16-B slots
     static constexpr int NZP = (NZ + 3) & ~3;
     static constexpr int NUP = (NU + 1) & ~1;
     static constexpr int NRECP = (M::NREC + 1) & ~1;
@@ -190,7 +190,7 @@ __device__ __forceinline__ void phase_defects(const DevConsts& c, int N, const d
 template <class M>
 __device__ void sweep_tables(const DevConsts& c, double* s, int lane) {
     using L = Lds<M>;
-    constexpr int NX = M::NX, NZ = M::NZ, NE = M::NE;
+    constexpr int NX = M::NX, NZ = M::NZ, NE = M::NE, NEV = M::NEV;
     for (int e = lane; e < L::TOTAL; e += kWave) s[e] = 0.0;
     wave_sync();
     for (int e = lane; e < M::NREC; e += kWave) s[L::REC + e] = 0.0;         // zero record -> constant part of F
@@ -199,8 +199,8 @@ __device__ void sweep_tables(const DevConsts& c, double* s, int lane) {
         const int j = e / NX, i = e % NX;
         s[L::FT + j * L::NIP + i] = M::F_entry(c, s + L::REC, i, j);
     }
-    for (int e = lane; e < NZ * NE; e += kWave) {
-        const int j = e / NE, m = e % NE;
+    for (int e = lane; e < NZ * NEV; e += kWave) {
+        const int j = e / NEV, m = e % NEV;
         s[L::FT + j * L::NIP + NX + m] = M::E_const(c, m, j);
     }
     int* ki = reinterpret_cast<int*>(s + L::KI);
@@ -240,9 +240,10 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
                                int lane, double& dV1, double& G1, double& G2, double& qu_inf, bool has_gap SDDP_T_ARG) {
     // has_gap = false: all defects are zero (every iteration after the first full step): v' = Vx, no Vxx d product
     using L = Lds<M>;
-    constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NREC = M::NREC, NP = M::NP;
+    constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NEV = M::NEV, NREC = M::NREC, NP = M::NP;
     constexpr int NXP = L::NXP, NIP = L::NIP, NZP = L::NZP, NUP = L::NUP;
     constexpr int NCOL = NU + 1 + NX;
+    static_assert(NEV == NE || !M::CONST_ROWS_STATE_WEIGHTED, "constant rows with node-dependent weights must stay in the product");
     constexpr int RREC = (NREC + kWave - 1) / kWave;
     constexpr bool PADROW = (NXP > NX);      // odd NX: the pad row of the Vxx tile carries v' through the W product
     static_assert(NCOL <= kWave, "one lane per augmented column");
@@ -258,6 +259,22 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
     for (int q = 0; q < PQ; ++q) codeq[q] = (lane + q * kWave < L::NTRIQ) ? ki[2 * NZP + lane + q * kWave] : 0;
 #pragma unroll
     for (int q = 0; q < PV; ++q) codev[q] = (lane + q * kWave < L::NTRIV) ? ki[2 * NZP + L::NTRIQ + lane + q * kWave] : 0;
+    // constant extra rows (m >= NEV): their share sum_m lambda_m E[m][row] E[m][col] of the lane's four Q entries, once per sweep
+    double qconst[PQ][4];
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        const int a0 = 2 * (codeq[q] >> 8), c0 = 2 * (codeq[q] & 255);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double v = 0.0;
+            if (NEV < NE) {
+                const int row = a0 + (e >> 1), col = c0 + (e & 1);
+                if (row < NZ && col < NZ)
+                    for (int m = NEV; m < NE; ++m) v += s[L::LG + m] * M::E_const(c, m, row) * M::E_const(c, m, col);
+            }
+            qconst[q][e] = v;
+        }
+    }
     // ---- terminal node: Vx = lx_N, Vxx = lxx_N = diag(D_state) + Je^T Lambda_state Je  (ddp.py:216-226)
     {
         const double* rN = rec + size_t(N) * NREC;
@@ -268,15 +285,15 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             const int a = e / NXP, b = e % NXP;
             double v = 0.0;
             if (a < NX && b < NX) {
-                for (int m = 0; m < NE; ++m) v += s[L::LS + m] * s[L::FT + a * NIP + NX + m] * s[L::FT + b * NIP + NX + m];
+                for (int m = 0; m < NEV; ++m) v += s[L::LS + m] * s[L::FT + a * NIP + NX + m] * s[L::FT + b * NIP + NX + m];
                 if (a == b) v += s[L::DS + a] + M::dparam(c, s + L::PK, ki[a], ki[NZP + a], 1.0, 0.0);
             }
             s[L::VXX + e] = v;
         }
         // extra-row part of WT = (V~ F~)^T for the nodes k >= 1: lambda_m Je[m][j].  Constant entries are written here once per
         // sweep, the per-knot variable ones by expand_var together with F~^T; node 0 (other weights) rescales them below
-        for (int e = lane; e < NZ * NE; e += kWave) {
-            const int j = e / NE, m = e % NE;
+        for (int e = lane; e < NZ * NEV; e += kWave) {
+            const int j = e / NEV, m = e % NEV;
             s[L::WT + j * NIP + NX + m] = s[L::LAM + m] * s[L::FT + j * NIP + NX + m];
         }
         wave_sync();
@@ -368,8 +385,8 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         }
         if (k == 0) {   // node 0 carries no state residuals: rescale the extra rows with the stage-only weights
             wave_sync();
-            for (int e = lane; e < NZ * NE; e += kWave) {
-                const int j = e / NE, m = e % NE;
+            for (int e = lane; e < NZ * NEV; e += kWave) {
+                const int j = e / NEV, m = e % NEV;
                 s[L::WT + j * NIP + NX + m] = s[L::LG + m] * s[L::FT + j * NIP + NX + m];
             }
         }
@@ -391,6 +408,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
                 q10 = fma(fb.y, wa.y, fma(fb.x, wa.x, q10));
                 q11 = fma(fb.y, wb.y, fma(fb.x, wb.x, q11));
             }
+            if (NEV < NE) { q00 += qconst[q][0]; q01 += qconst[q][1]; q10 += qconst[q][2]; q11 += qconst[q][3]; }
             if (a0 == c0) {   // diagonal block: add D, keep it exactly symmetric
                 const double d0 = state * s[L::DS + a0] + s[L::DG + a0] + M::dparam(c, s + L::PK, ki[a0], ki[NZP + a0], state, 1.0);
                 const double d1 = state * s[L::DS + a0 + 1] + s[L::DG + a0 + 1] + M::dparam(c, s + L::PK, ki[a0 + 1], ki[NZP + a0 + 1], state, 1.0);

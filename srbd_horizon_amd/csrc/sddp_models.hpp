@@ -635,6 +635,11 @@ struct SrbdModel {
     // Q = diag(D) + F~^T V~ F~ needs no special cases.  Only the wdot rows (A) and the quaternion blocks vary per knot.
     // -------------------------------------------------------------------------------------------------------------
     static constexpr int NE = 6 + (CS ? 4 + NC : 0);   // wdot(3) rddot(3) [rel_pos(4) rel_vel(NC)]
+    // Extra rows m >= NEV are constant (E_const) and their weights do not depend on the node: their contribution
+    // sum_m lambda_m e_m e_m^T to Q is a constant matrix that the one-wave kernel adds instead of carrying the rows through the
+    // tile products (srbd13: the three rddot rows -> product depth 20 -> 16).  NEV = NE: every row goes through the product.
+    static constexpr int NEV = CS ? NE : 3;
+    static constexpr bool CONST_ROWS_STATE_WEIGHTED = CS;      // rel_pos rows carry state-node weights (lam_state)
     static constexpr int NVAR = 28 + 3 * NA;           // per-knot variable entries: quaternion blocks + A
 
     // constant entry of extra row m w.r.t. z_j (one-time table fill; variable wdot rows are 0 here)
@@ -953,6 +958,8 @@ struct LipModel {
     }
     // ---- branch-free expansion hooks (see SrbdModel): everything is constant, all couplings are extra rows
     static constexpr int NE = 16;   // rxy(2) zmp(3) rddot(3) rel_pos(4) rel_vel(4)
+    static constexpr int NEV = NE;
+    static constexpr bool CONST_ROWS_STATE_WEIGHTED = true;
     __device__ static double E_const(const DevConsts& c, int m, int j) {
         int cls, ci, ax;
         decode(j, cls, ci, ax);
