@@ -101,6 +101,7 @@ struct Lds {
     static constexpr int NXP = (NX + 1) & ~1;
     static constexpr int NIP = (((NI + 1) & ~1) % 4 == 0) ? ((NI + 1) & ~1) + 2 : ((NI + 1) & ~1);   // even, == 2 (mod 4): rows on distinct 16-B slots
     static constexpr int NZP = (NZ + 3) & ~3;
+    static constexpr int SQ = (NZP % 4 == 0) ? NZP + 2 : NZP;          // row stride of the Q tile: == 2 (mod 4) as well
     static constexpr int NUP = (NU + 1) & ~1;
     static constexpr int NRECP = (M::NREC + 1) & ~1;
     static constexpr int NPP = (M::NP + 1) & ~1;
@@ -108,7 +109,7 @@ struct Lds {
     static constexpr int FT = VXX + NXP * NXP;
     static constexpr int WT = FT + NZP * NIP;
     static constexpr int Q = WT + NZP * NIP;
-    static constexpr int VX = Q + NZP * NZP;
+    static constexpr int VX = Q + NZP * SQ;
     static constexpr int VP = VX + NXP;
     static constexpr int DK = VP + NXP;
     static constexpr int QV = DK + NXP;
@@ -241,7 +242,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
     // has_gap = false: all defects are zero (every iteration after the first full step): v' = Vx, no Vxx d product
     using L = Lds<M>;
     constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NEV = M::NEV, NREC = M::NREC, NP = M::NP;
-    constexpr int NXP = L::NXP, NIP = L::NIP, NZP = L::NZP, NUP = L::NUP;
+    constexpr int NXP = L::NXP, NIP = L::NIP, NZP = L::NZP, NUP = L::NUP, SQ = L::SQ;
     constexpr int NCOL = NU + 1 + NX;
     static_assert(NEV == NE || !M::CONST_ROWS_STATE_WEIGHTED, "constant rows with node-dependent weights must stay in the product");
     constexpr int RREC = (NREC + kWave - 1) / kWave;
@@ -419,13 +420,13 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             }
             double2_t r0, r1;
             r0.x = q00; r0.y = q01; r1.x = q10; r1.y = q11;
-            *reinterpret_cast<double2_t*>(s + L::Q + a0 * NZP + c0) = r0;
-            *reinterpret_cast<double2_t*>(s + L::Q + (a0 + 1) * NZP + c0) = r1;
+            *reinterpret_cast<double2_t*>(s + L::Q + a0 * SQ + c0) = r0;
+            *reinterpret_cast<double2_t*>(s + L::Q + (a0 + 1) * SQ + c0) = r1;
             if (a0 != c0) {
                 double2_t m0, m1;
                 m0.x = q00; m0.y = q10; m1.x = q01; m1.y = q11;
-                *reinterpret_cast<double2_t*>(s + L::Q + c0 * NZP + a0) = m0;
-                *reinterpret_cast<double2_t*>(s + L::Q + (c0 + 1) * NZP + a0) = m1;
+                *reinterpret_cast<double2_t*>(s + L::Q + c0 * SQ + a0) = m0;
+                *reinterpret_cast<double2_t*>(s + L::Q + (c0 + 1) * SQ + a0) = m1;
             }
         }
         if (!PADROW) {
@@ -441,7 +442,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         }
         wave_sync();
         if (theta != 0.0) {   // exact second-order torque term (wave-uniform switch)
-            M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, NZP, theta, lane, kWave);
+            M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, SQ, theta, lane, kWave);
             wave_sync();
         }
         SDDP_TICK(4)
@@ -453,7 +454,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 const double qv = s[L::QV + NX + i];
-                double v = s[L::Q + (NX + i) * NZP + qcol];
+                double v = s[L::Q + (NX + i) * SQ + qcol];
                 v = lane == NU ? qv : v;
                 v += (i == lane) ? mu : 0.0;
                 a[i] = lane < NCOL ? v : 0.0;
@@ -508,10 +509,10 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             const int a0 = code >> 8, c0 = 2 * (code & 255);        // row a0, columns c0, c0 + 1 (c0 <= a0)
             const bool two = c0 + 1 <= a0;                          // the second column is in the lower triangle too
             const int c1 = two ? c0 + 1 : c0;
-            double v0 = s[L::Q + a0 * NZP + c0], v1 = s[L::Q + a0 * NZP + c1];
+            double v0 = s[L::Q + a0 * SQ + c0], v1 = s[L::Q + a0 * SQ + c1];
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                const double qa = s[L::Q + a0 * NZP + NX + i];
+                const double qa = s[L::Q + a0 * SQ + NX + i];
                 v0 = fma(qa, s[L::KT + c0 * NUP + i], v0);
                 v1 = fma(qa, s[L::KT + c1 * NUP + i], v1);
             }
