@@ -222,6 +222,10 @@ def main():
         "mean_iters": float(np.mean(iters)), "max_iters_hit_frac": float(np.mean(st["status"] == 1)),
         "converged_frac": float(np.mean(st["converged"] == 1)), "mean_rollouts": float(np.mean(rollouts)),
         "iterations_per_s": world * float(np.sum(iters)) * args.steps / elapsed,
+        # secondary: ~0.85 Mflop of fp64 per DDP iteration at (N, nx, nu) = (30, 13, 6) (dense backward
+        # sweep 25.2 kflop/knot + model evaluation + one rollout), against the MI355X fp64 vector peak of 78.6 TFLOP/s
+        "fp64_algorithmic_tflops": world * float(np.sum(iters)) * args.steps / elapsed * 0.85e6 * (N / 30.0) / 1e12,
+        "fp64_vector_peak_frac": float(np.sum(iters)) * args.steps / elapsed * 0.85e6 * (N / 30.0) / 78.6e12,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic() if (B == 1024 and N == 30) else None, "kernel": ("solve_kernel_w2" if wps >= 2 else "solve_kernel") + "<SrbdModel<2,false>>", "kernel_ms": kms,
                      "algorithmic_bytes_per_launch": abytes,
