@@ -15,15 +15,17 @@
 #define NU 6
 #define NZ 19
 #define NP 19
-#define NR 29 /* residual rows of a stage node: 11 state + 18 input */
+#define NR 39 /* residual rows of a stage node: 11 state + 18 input (+ 10 friction-cone barrier rows when enabled) */
 #define GRAV 9.81
 
 typedef struct {
     double dt, inv_ms, Is[9], com_z, w_rz, w_rd, w_w, w_f, w_sw, gq, lever;
+    double mu_lin, bar_w, bar_s;   /* friction-cone exponential barrier (oracle/models.py _force_rows): off when bar_w == 0 */
     int inertia_mode;
 } consts_t;
 
-/* packed constants from Python: m, I[9], com_z, dt, force_scaling, r_gain, rdot_gain, w_gain, fsw, qddot, minf, inertia_mode, lever */
+/* packed constants from Python: m, I[9], com_z, dt, force_scaling, r_gain, rdot_gain, w_gain, fsw, qddot, minf, inertia_mode, lever,
+ * friction_cone_coefficient, friction_barrier_weight, friction_barrier_sharpness */
 static void unpack_consts(const double* c, consts_t* k) {
     const double m = c[0], fs = c[12];
     k->inv_ms = fs / m;
@@ -32,6 +34,7 @@ static void unpack_consts(const double* c, consts_t* k) {
     k->w_rz = c[13]; k->w_rd = c[14]; k->w_w = c[15];
     k->w_sw = fs * fs * c[16]; k->gq = c[17]; k->w_f = fs * fs * c[18];
     k->inertia_mode = (int)c[19]; k->lever = c[20];
+    k->mu_lin = c[21] / sqrt(2.0); k->bar_w = c[22]; k->bar_s = c[23];
 }
 
 static void cross(const double* a, const double* b, double* o) {
@@ -212,6 +215,17 @@ static int residual(const consts_t* c, const double* x, const double* u, const d
             n += 3;
             for (int a = 0; a < 3; ++a) { r[n + a] = g2 * u[3 * i + a]; if (J) J[(n + a) * NZ + NX + 3 * i + a] = g2; }
             n += 3;
+            if (c->bar_w > 0.0) {   /* r_j = sqrt(w) exp(s a_j.f / 2), rows of the linearised cone A f <= 0 */
+                const double ml = c->mu_lin;
+                const double A[5][3] = {{1, 0, -ml}, {-1, 0, -ml}, {0, 1, -ml}, {0, -1, -ml}, {0, 0, -1}};
+                for (int j = 0; j < 5; ++j) {
+                    const double gj = A[j][0] * u[3 * i] + A[j][1] * u[3 * i + 1] + A[j][2] * u[3 * i + 2];
+                    const double rj = sqrt(c->bar_w) * exp(0.5 * c->bar_s * gj);
+                    r[n + j] = rj;
+                    if (J) for (int a = 0; a < 3; ++a) J[(n + j) * NZ + NX + 3 * i + a] = 0.5 * c->bar_s * rj * A[j][a];
+                }
+                n += 5;
+            }
         }
     }
     return n;

@@ -23,7 +23,8 @@ def pack_consts(cst):
     """cst: oracle.models.RobotConsts"""
     return np.array([cst.m, *np.asarray(cst.I, dtype=float).reshape(-1), cst.com[2], cst.dt, cst.force_scaling,
                      cst.r_tracking_gain, cst.rdot_tracking_gain, cst.w_tracking_gain, cst.force_switch_weight,
-                     cst.min_qddot_gain, cst.min_f_gain, float(cst.inertia_mode), cst.lever_sign], dtype=np.float64)
+                     cst.min_qddot_gain, cst.min_f_gain, float(cst.inertia_mode), cst.lever_sign,
+                     cst.friction_cone_coefficient, cst.friction_barrier_weight, cst.friction_barrier_sharpness], dtype=np.float64)
 
 
 def pack_opts(o):

