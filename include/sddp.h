@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDDP_ABI_VERSION 2
+#define SDDP_ABI_VERSION 3
 
 /* model ids */
 #define SDDP_MODEL_SRBD13 0 /* nx=13 nu=6  np=19 : BASELINE.json metric model (contacts are per-knot parameters) */
@@ -70,6 +70,13 @@ typedef struct sddp_model_consts {
     double lip_height;     /* 0.88                                 prb.py:317   */
     int    inertia_mode;   /* 0: R o I o R^T element-wise (reference-faithful, prb.py:99); 1: R I R^T */
     double lever_sign;     /* +1: (c - r) x f ; -1: (r - c) x f    */
+    /* Inequality handling the reference collects and ignores (friction cone prb.py:172-177, exponential barrier ddp.py:197-202,
+     * both commented out upstream).  friction_barrier_weight = 0 (default) = the reference's behaviour.  > 0 adds, per contact
+     * force and stage node, weight * sum_j exp(sharpness * a_j.f) over the 5 rows of the linearised cone A f <= 0
+     * (inner pyramid mu / sqrt(2), unilateral f_z >= 0), with Gauss-Newton Hessians like every other cost. */
+    double friction_cone_coefficient;  /* 0.8, rosparam default prb.py:174 */
+    double friction_barrier_weight;    /* 0 = off */
+    double friction_barrier_sharpness; /* 1 */
 } sddp_model_consts;
 
 /* per-instance solve record (what pyddp exposes only as is_converged(), ddp.py:106, plus the tic/toc of

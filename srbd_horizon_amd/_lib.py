@@ -34,7 +34,8 @@ class SddpModelConsts(C.Structure):
                 ("r_tracking_gain", C.c_double), ("rdot_tracking_gain", C.c_double), ("w_tracking_gain", C.c_double),
                 ("rel_pos_gain", C.c_double), ("force_switch_weight", C.c_double), ("min_qddot_gain", C.c_double),
                 ("min_f_gain", C.c_double), ("zmp_tracking_gain", C.c_double), ("lip_height", C.c_double),
-                ("inertia_mode", C.c_int), ("lever_sign", C.c_double)]
+                ("inertia_mode", C.c_int), ("lever_sign", C.c_double), ("friction_cone_coefficient", C.c_double),
+                ("friction_barrier_weight", C.c_double), ("friction_barrier_sharpness", C.c_double)]
 
 
 class SddpStats(C.Structure):
@@ -123,7 +124,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.sddp_abi_version() != 2:
+    if lib.sddp_abi_version() != 3:
         raise RuntimeError("libsddp_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -26,10 +26,11 @@ struct Dims {
     size_t lds;
 };
 
-bool model_dims(int id, Dims& d) {
+// bar: the friction-cone barrier build of the SRBD models (longer derivative record)
+bool model_dims(int id, Dims& d, bool bar = false) {
     switch (id) {
-        case SDDP_MODEL_SRBD13: d = {Srbd13::NX, Srbd13::NU, Srbd13::NP, Srbd13::NREC, Lds<Srbd13>::BYTES}; return true;
-        case SDDP_MODEL_SRBD37: d = {Srbd37::NX, Srbd37::NU, Srbd37::NP, Srbd37::NREC, Lds<Srbd37>::BYTES}; return true;
+        case SDDP_MODEL_SRBD13: d = {Srbd13::NX, Srbd13::NU, Srbd13::NP, bar ? Srbd13B::NREC : Srbd13::NREC, Lds<Srbd13>::BYTES}; return true;
+        case SDDP_MODEL_SRBD37: d = {Srbd37::NX, Srbd37::NU, Srbd37::NP, bar ? Srbd37B::NREC : Srbd37::NREC, Lds<Srbd37>::BYTES}; return true;
         case SDDP_MODEL_LIP30: d = {Lip30::NX, Lip30::NU, Lip30::NP, Lip30::NREC, Lds<Lip30>::BYTES}; return true;
         default: return false;
     }
@@ -57,6 +58,7 @@ struct sddp_handle {
     long long n_ms = 0;
     std::string err;
     bool have_x0 = false, have_xws = false, have_uws = false, have_params = false;
+    bool bar = false;               // friction-cone barrier build (consts.friction_barrier_weight > 0)
     double* tick_in = nullptr;      // [B][np + nx] staging of sddp_advance
 
     size_t n_x() const { return size_t(B) * (N + 1) * d.nx; }
@@ -164,8 +166,8 @@ int launch_forward(sddp_handle* h, const SolveArgs& a) {
 
 #define DISPATCH(h, fn, ...)                                                 \
     switch ((h)->model_id) {                                                 \
-        case SDDP_MODEL_SRBD13: rc = fn<Srbd13>(__VA_ARGS__); break;          \
-        case SDDP_MODEL_SRBD37: rc = fn<Srbd37>(__VA_ARGS__); break;          \
+        case SDDP_MODEL_SRBD13: rc = (h)->bar ? fn<Srbd13B>(__VA_ARGS__) : fn<Srbd13>(__VA_ARGS__); break; \
+        case SDDP_MODEL_SRBD37: rc = (h)->bar ? fn<Srbd37B>(__VA_ARGS__) : fn<Srbd37>(__VA_ARGS__); break; \
         case SDDP_MODEL_LIP30: rc = fn<Lip30>(__VA_ARGS__); break;            \
         default: rc = SDDP_ERR_MODEL;                                         \
     }
@@ -238,6 +240,9 @@ void sddp_default_consts(sddp_model_consts* c) {
     c->lip_height = 0.88;
     c->inertia_mode = 0;
     c->lever_sign = 1.0;
+    c->friction_cone_coefficient = 0.8;      // prb.py:174
+    c->friction_barrier_weight = 0.0;        // off: the reference ignores its inequality constraints (ddp.py:197-209)
+    c->friction_barrier_sharpness = 1.0;
 }
 
 const char* sddp_last_error(const sddp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -246,14 +251,17 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (!out) return fail(nullptr, SDDP_ERR_ARG, "out is NULL");
     *out = nullptr;
     Dims d;
-    if (!model_dims(model_id, d)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
+    const bool bar = consts && consts->friction_barrier_weight > 0.0 && model_id != SDDP_MODEL_LIP30;
+    if (!model_dims(model_id, d, bar)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
     if (N < 1 || batch < 1) return fail(nullptr, SDDP_ERR_ARG, "N and batch must be >= 1");
+    if (consts && (consts->friction_barrier_weight < 0.0 || (bar && !(consts->friction_cone_coefficient > 0.0))))
+        return fail(nullptr, SDDP_ERR_ARG, "friction_barrier_weight must be >= 0 and friction_cone_coefficient > 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, SDDP_ERR_HIP, "no HIP device visible: the SDDP engine has no CPU fallback");
     sddp_handle* h = new (std::nothrow) sddp_handle();
     if (!h) return fail(nullptr, SDDP_ERR_NOMEM, "out of host memory");
-    h->model_id = model_id; h->N = N; h->B = batch; h->d = d;
+    h->model_id = model_id; h->N = N; h->B = batch; h->d = d; h->bar = bar;
     if (opts) h->opts = *opts; else sddp_default_options(&h->opts);
     if (consts) h->consts = *consts; else sddp_default_consts(&h->consts);
     int rc = validate_options(h, h->opts);
@@ -486,10 +494,11 @@ int sddp_kernel_time_stats(sddp_handle* h, double* sum_ms, long long* count, int
 int sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk, const int* k, const double* x,
                     const double* u, const double* p, double* f_out, double* F_out, double* H_out, double* g_out, double* L_out) {
     Dims d;
-    if (!model_dims(model_id, d)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
-    if (nk < 1 || !k || !x || !u || !p) return fail(nullptr, SDDP_ERR_ARG, "bad argument");
     sddp_model_consts cc;
     if (consts) cc = *consts; else sddp_default_consts(&cc);
+    const bool bar = cc.friction_barrier_weight > 0.0 && model_id != SDDP_MODEL_LIP30;
+    if (!model_dims(model_id, d, bar)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
+    if (nk < 1 || !k || !x || !u || !p) return fail(nullptr, SDDP_ERR_ARG, "bad argument");
     const DevConsts dc = make_dev_consts(cc);
     const int nz = d.nx + d.nu;
     const size_t D = sizeof(double);
@@ -512,8 +521,14 @@ int sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk
     TRY0(hipMemcpy(dp, p, size_t(nk) * d.np * D, hipMemcpyHostToDevice));
     TRY0(hipMemset(drec, 0, size_t(nk) * d.nrec * D));
     switch (model_id) {
-        case SDDP_MODEL_SRBD13: hipLaunchKernelGGL(eval_knots_kernel<Srbd13>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL); break;
-        case SDDP_MODEL_SRBD37: hipLaunchKernelGGL(eval_knots_kernel<Srbd37>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL); break;
+        case SDDP_MODEL_SRBD13:
+            if (bar) hipLaunchKernelGGL(eval_knots_kernel<Srbd13B>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL);
+            else hipLaunchKernelGGL(eval_knots_kernel<Srbd13>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL);
+            break;
+        case SDDP_MODEL_SRBD37:
+            if (bar) hipLaunchKernelGGL(eval_knots_kernel<Srbd37B>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL);
+            else hipLaunchKernelGGL(eval_knots_kernel<Srbd37>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL);
+            break;
         case SDDP_MODEL_LIP30: hipLaunchKernelGGL(eval_knots_kernel<Lip30>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL); break;
     }
     TRY0(hipGetLastError());

@@ -445,6 +445,10 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, SQ, theta, lane, kWave);
             wave_sync();
         }
+        if (M::BAR) {         // friction-cone barrier builds: its Hessian blocks on the force-force diagonal of Q
+            M::add_barrier(s + L::REC, s + L::Q, SQ, lane, kWave);
+            wave_sync();
+        }
         SDDP_TICK(4)
         // ---- [k K] = -Quu^-1 [Qu Qux]: Gauss-Jordan, lane j owns column j of [Quu+mu I | Qu | Qux]
         double a[NU];

@@ -284,6 +284,10 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, SQ, theta, tid, kThreadsMW);
             __syncthreads();
         }
+        if (M::BAR) {         // friction-cone barrier builds: its Hessian blocks on the force-force diagonal of Q
+            M::add_barrier(s + L::REC, s + L::Q, SQ, tid, kThreadsMW);
+            __syncthreads();
+        }
         SDDP_TICK(4)
         // ---- [k K] = -Quu^-1 [Qu Qux]: block Gauss-Jordan, lane j = column j of [Quu+mu I | Qu | Qux], wave w = rows w RPW ..
         {

@@ -28,6 +28,7 @@ struct DevConsts {
     double w_rz, w_rd, w_w, w_rel, w_f, w_sw, gq, w_pen, w_zmp, w_rxy, eta2;
     double d1x, d1y, d2x, d2y;  // rel_pos offsets d1 = p2 - p0, d2 = p3 - p1 (prb.py:153-154)
     double lever;
+    double mu_lin, bar_w, bar_s;   // friction-cone exponential barrier (BAR models only): linearised coefficient, weight, sharpness
     int inertia_mode;
 };
 
@@ -54,6 +55,9 @@ inline DevConsts make_dev_consts(const sddp_model_consts& c) {
     d.d2y = c.feet[10] - c.feet[4];
     d.lever = c.lever_sign;
     d.inertia_mode = c.inertia_mode;
+    d.mu_lin = c.friction_cone_coefficient / sqrt(2.0);
+    d.bar_w = c.friction_barrier_weight;
+    d.bar_s = c.friction_barrier_sharpness;
     return d;
 }
 
@@ -184,10 +188,11 @@ __device__ __forceinline__ void world_inertia_d(const DevConsts& c, const double
 // SRBD family.  CS=false, NC=2: srbd13 (metric model, contacts are parameters);  CS=true, NC=4: srbd37
 // (reference problem, contacts are states -- prb.py:32-68).
 // ---------------------------------------------------------------------------------------------------------
-template <int NC_, bool CS_>
+template <int NC_, bool CS_, bool BAR_ = false>
 struct SrbdModel {
     static constexpr int NC = NC_;
     static constexpr bool CS = CS_;
+    static constexpr bool BAR = BAR_;      // friction-cone exponential barrier on the contact forces (sddp.h), separate builds
     static constexpr int NX = CS ? 13 + 6 * NC : 13;
     static constexpr int NU = CS ? 6 * NC : 3 * NC;
     static constexpr int NZ = NX + NU;
@@ -198,7 +203,9 @@ struct SrbdModel {
     // compact columns of A = d wdot / d z : r(0..2) o(3..6) w(7..9) [c(3NC)] f(3NC)
     static constexpr int AC = 10, AF = 10 + (CS ? 3 * NC : 0), NA = AF + 3 * NC;
     // derivative record of one knot
-    static constexpr int REC_A = 0, REC_JO = 3 * NA, REC_JW = REC_JO + 16, REC_MI = REC_JW + 12, REC_G = REC_MI + 9, NREC = REC_G + NZ;
+    static constexpr int REC_A = 0, REC_JO = 3 * NA, REC_JW = REC_JO + 16, REC_MI = REC_JW + 12, REC_G = REC_MI + 9,
+                         REC_B = REC_G + NZ,                       // BAR: barrier Hessian per contact: hxx hyy hzz hxz hyz
+                         NREC = REC_B + (BAR ? 5 * NC : 0);
 
     __device__ __forceinline__ static int uf(int i) { return CS ? 6 * i + 3 : 3 * i; }  // prb.py:66-68 interleaved
     // parameter layouts: srbd37 = creation order; srbd13 = App. A.7
@@ -276,6 +283,37 @@ struct SrbdModel {
         return L;
     }
 
+    // friction-cone exponential barrier of one contact force (BAR builds): value w sum_j exp(s a_j.f) over the rows
+    // a_j = (+-1, 0, -mu), (0, +-1, -mu), (0, 0, -1) of the linearised cone; gradient; Gauss-Newton Hessian of the residual form
+    // r_j = sqrt(w) exp(s a_j.f / 2), i.e. (w s^2 / 2) sum_j e_j a_j a_j^T -> hxx hyy hzz hxz hyz (hxy = 0)
+    __device__ __forceinline__ static double barrier(const DevConsts& c, const double* f, double* grad, double* h) {
+        const double m = c.mu_lin, sz = -m * f[2];
+        const double e1 = exp(c.bar_s * (f[0] + sz)), e2 = exp(c.bar_s * (-f[0] + sz));
+        const double e3 = exp(c.bar_s * (f[1] + sz)), e4 = exp(c.bar_s * (-f[1] + sz));
+        const double e5 = exp(-c.bar_s * f[2]);
+        if (grad) {
+            const double ws = c.bar_w * c.bar_s;
+            grad[0] = ws * (e1 - e2);
+            grad[1] = ws * (e3 - e4);
+            grad[2] = -ws * (m * (e1 + e2 + e3 + e4) + e5);
+        }
+        if (h) {
+            const double k2 = 0.5 * c.bar_w * c.bar_s * c.bar_s;
+            h[0] = k2 * (e1 + e2);
+            h[1] = k2 * (e3 + e4);
+            h[2] = k2 * (m * m * (e1 + e2 + e3 + e4) + e5);
+            h[3] = -k2 * m * (e1 - e2);
+            h[4] = -k2 * m * (e3 - e4);
+        }
+        return c.bar_w * (e1 + e2 + e3 + e4 + e5);
+    }
+    // entry (a, b) of that 3x3 Hessian from its 5 stored words
+    __device__ __forceinline__ static double barrier_h(const double* h, int a, int b) {
+        if (a == b) return h[a];
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        return hi == 2 ? h[3 + lo] : 0.0;
+    }
+
     // cost of the input residuals + penalties given rddot/wdot (nodes 0..ns-1, prb.py:200-204, :166-181)
     template <class XV, class UV>
     __device__ __forceinline__ static double input_cost(const DevConsts& c, XV x, UV u, const double* p,
@@ -288,6 +326,7 @@ struct SrbdModel {
             const double s1 = 1.0 - p_sw(p, i);
             const double wf = c.w_f + c.w_sw * s1 * s1;
             L += wf * (f[i][0] * f[i][0] + f[i][1] * f[i][1] + f[i][2] * f[i][2]);
+            if (BAR) L += barrier(c, f[i], nullptr, nullptr);
         }
         if (CS) {
 #pragma unroll
@@ -484,6 +523,14 @@ struct SrbdModel {
                 const double wf = 2 * (c.w_f + c.w_sw * s1 * s1);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) g[NX + uf(i) + a] += s * q.rddot[a] * c.inv_ms + wf * f[i][a];
+                if (BAR) {
+                    double bg[3], bh[5];
+                    barrier(c, f[i], bg, bh);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) g[NX + uf(i) + a] += bg[a];
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) rec[REC_B + 5 * i + t] = bh[t];
+                }
             }
             if (CS) {
                 const double sp = 2 * c.w_pen;
@@ -619,6 +666,7 @@ struct SrbdModel {
                 default: break;
             }
         }
+        if (BAR && stage && cli == V_F && clj == V_F && ci == cj) v += barrier_h(rec + REC_B + 5 * ci, ai, aj);
         if (stage) {
             const int a = acol(i), b = acol(j);
             if (a >= 0 && b >= 0)
@@ -759,6 +807,13 @@ struct SrbdModel {
         }
     }
 
+    // BAR builds: the barrier's Gauss-Newton Hessian blocks (3x3 per contact force, from the record) added to Quu
+    __device__ __forceinline__ static void add_barrier(const double* rec, double* Q, int ld, int lane, int nlanes) {
+        for (int e = lane; e < 9 * NC; e += nlanes) {
+            const int i = e / 9, a = (e % 9) / 3, b = e % 3;
+            Q[(NX + uf(i) + a) * ld + NX + uf(i) + b] += barrier_h(rec + REC_B + 5 * i, a, b);
+        }
+    }
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -767,6 +822,8 @@ struct SrbdModel {
 // ---------------------------------------------------------------------------------------------------------
 struct LipModel {
     static constexpr int NC = 4;
+    static constexpr bool BAR = false;
+    __device__ __forceinline__ static void add_barrier(const double*, double*, int, int, int) {}
     static constexpr int NX = 30, NU = 15, NZ = 45, NP = 11;
     static constexpr int XR = 0, XC = 3, XRD = 15, XCD = 18;
     static constexpr int REC_G = 0, NREC = NZ;
@@ -1019,6 +1076,8 @@ struct LipModel {
 
 using Srbd13 = SrbdModel<2, false>;
 using Srbd37 = SrbdModel<4, true>;
+using Srbd13B = SrbdModel<2, false, true>;   // with the friction-cone barrier (sddp_model_consts.friction_barrier_weight > 0)
+using Srbd37B = SrbdModel<4, true, true>;
 using Lip30 = LipModel;
 
 }  // namespace sddp

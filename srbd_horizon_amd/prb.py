@@ -33,7 +33,9 @@ class RobotModel:
 # rosparam names and defaults (prb.py:39-40, :142-150, :358-362)
 DEFAULT_PARAMS = dict(contact_model=2, number_of_legs=2, r_tracking_gain=1e3, rdot_tracking_gain=1e4, w_tracking_gain=1e4,
                       rel_position_gain=1e4, force_switch_weight=1e2, min_qddot_gain=1e0, min_f_gain=1e-2,
-                      zmp_tracking_gain=1e3, inertia_mode=0, lever_sign=1.0)
+                      zmp_tracking_gain=1e3, inertia_mode=0, lever_sign=1.0,
+                      # prb.py:174 rosparam; the barrier is this build's opt-in for the inequality handling the reference disables
+                      friction_cone_coefficient=0.8, friction_barrier_weight=0.0, friction_barrier_sharpness=1.0)
 
 
 def quat_inverse(q):
@@ -49,7 +51,10 @@ def _consts(robot: RobotModel, prm: dict, dt: float, feet) -> dict:
                 w_tracking_gain=prm["w_tracking_gain"], rel_pos_gain=prm["rel_position_gain"],
                 force_switch_weight=prm["force_switch_weight"], min_qddot_gain=prm["min_qddot_gain"],
                 min_f_gain=prm["min_f_gain"], zmp_tracking_gain=prm["zmp_tracking_gain"], lip_height=0.88,
-                inertia_mode=int(prm["inertia_mode"]), lever_sign=float(prm["lever_sign"]))
+                inertia_mode=int(prm["inertia_mode"]), lever_sign=float(prm["lever_sign"]),
+                friction_cone_coefficient=float(prm["friction_cone_coefficient"]),
+                friction_barrier_weight=float(prm["friction_barrier_weight"]),
+                friction_barrier_sharpness=float(prm["friction_barrier_sharpness"]))
 
 
 class SRBDProblem:

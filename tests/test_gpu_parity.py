@@ -330,3 +330,57 @@ def test_extreme_horizons_and_ragged_batches(name, N, B):
         assert st["iters"][b] == r.iters and bool(st["converged"][b]) == r.converged
         assert np.max(np.abs(x[b] - r.xs)) <= 1e-6 and np.max(np.abs(u[b] - r.us)) <= 1e-6
         assert abs(st["cost"][b] - r.cost) <= 1e-9 * max(1.0, abs(r.cost))
+
+
+BARRIER = dict(friction_barrier_weight=6.0, friction_barrier_sharpness=30.0, friction_cone_coefficient=0.8)
+
+
+@pytest.mark.parametrize("name", ["srbd13", "srbd37"])
+def test_friction_cone_barrier_knots_match_oracle(name):
+    """SURVEY 8(f) item 3 -- the inequality handling the reference disables (prb.py:172-177, ddp.py:197-202), as an opt-in
+    exponential barrier on the contact forces: per-knot value, gradient and Gauss-Newton Hessian of the barrier builds."""
+    N = 20
+    m = _oracle_model(name, BARRIER)
+    rng = np.random.default_rng(9)
+    ks = np.array([0, 1, 7, N - 1, N], dtype=np.int32)
+    nk = len(ks)
+    X = np.tile(m.initial_state(), (nk, 1)) + 0.05 * rng.standard_normal((nk, m.nx))
+    U = np.tile(m.static_input(), (nk, 1)) + 0.05 * rng.standard_normal((nk, m.nu))
+    P = np.tile(m.default_params(N)[3], (nk, 1)) + 0.05 * rng.standard_normal((nk, m.np_))
+    f, F, H, g, L = eval_knots(name, N, ks, X, U, P, consts=BARRIER)
+    f0, F0, H0, g0, L0 = eval_knots(name, N, ks, X, U, P)
+    assert np.all(L[:-1] > L0[:-1]) and L[-1] == L0[-1]                  # stage nodes carry the barrier, the terminal node not
+    np.testing.assert_array_equal(f, f0)
+    for t, k in enumerate(ks[:-1]):
+        Lo, lx, lu, lxx, lux, luu = m.cost_derivs(X[t], U[t], P[t], int(k))
+        Ho = np.block([[lxx, lux.T], [lux, luu]])
+        go = np.concatenate([lx, lu])
+        assert abs(L[t] - Lo) <= 1e-12 * max(1.0, abs(Lo))
+        np.testing.assert_allclose(g[t], go, rtol=1e-11, atol=1e-11 * max(1.0, np.max(np.abs(go))))
+        np.testing.assert_allclose(H[t], Ho, rtol=1e-11, atol=1e-11 * max(1.0, np.max(np.abs(Ho))))
+
+
+@pytest.mark.parametrize("name,N", [("srbd13", 30), ("srbd37", 20)])
+def test_friction_cone_barrier_solve_matches_oracle_and_tightens_the_cone(name, N):
+    seeds = [0, 1, 6]
+    batch = workload.make_batch(name, N, seeds)
+    m = _oracle_model(name, BARRIER)
+    res = {}
+    for tag, consts in (("off", dict(batch["consts"])), ("on", dict(batch["consts"], **BARRIER))):
+        eng = DdpEngine(name, N, len(seeds), opts=_opts(), consts=consts)
+        eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+        x, u = eng.solve(batch["params"])
+        res[tag] = (x, u, eng.stats.copy())
+    x, u, st = res["on"]
+    for b in range(len(seeds)):
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], _oracle_opts())
+        assert st["iters"][b] == r.iters and bool(st["converged"][b]) == r.converged
+        assert np.max(np.abs(x[b] - r.xs)) <= 1e-6 and np.max(np.abs(u[b] - r.us)) <= 1e-6
+        assert abs(st["cost"][b] - r.cost) <= 1e-9 * abs(r.cost)
+    # worst violation of the linearised cone A f <= 0 over all knots and contacts shrinks when the barrier is on
+    A = omodels.friction_cone_rows(0.8)
+    fcols = [slice(3 * i, 3 * i + 3) for i in range(2)] if name == "srbd13" else [slice(6 * i + 3, 6 * i + 6) for i in range(4)]
+    viol = {t: max(float(np.max(res[t][1][..., c] @ A.T)) for c in fcols) for t in res}
+    assert viol["on"] < viol["off"] or viol["off"] <= 0.0, viol
+    with pytest.raises(RuntimeError, match="friction"):
+        DdpEngine(name, N, 1, consts=dict(friction_barrier_weight=-1.0))
