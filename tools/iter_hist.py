@@ -1,6 +1,7 @@
 """Iteration / rollout distribution over the bench batch (which instances set the batch time)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), numpy as np
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from srbd_horizon_amd import workload
 from srbd_horizon_amd.engine import DdpEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

@@ -1,6 +1,6 @@
 """Per-tick solve time of the receding-horizon loop (MpcLoop) for one model: median / mean ms and iterations per tick."""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), time
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from srbd_horizon_amd.mpc import MpcLoop
 
