@@ -469,12 +469,17 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
         SDDP_TICK(8)
         const double* sb = s + L::RO_S + (k & 1) * L::SB_N;
         // ---- A: wave 0 closes the previous knot: x_k = f(x_{k-1}, u_{k-1}) - (1 - alpha) d_{k-1}
-        if (wave == 0) {
-            if (k == 0 || OPEN_LOOP) { for (int i = 0; i < NX; ++i) X[i] = Y[i]; }
-            else {
+        if (wave == 0) {   // all loads before the first store: the compiler cannot tell the X and Y columns apart
+            double t[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) t[i] = Y[i];
+            if (!(k == 0 || OPEN_LOOP)) {
                 const double* dprev = s + L::RO_S + ((k - 1) & 1) * L::SB_N + L::SB_D;
-                for (int i = 0; i < NX; ++i) X[i] = Y[i] - oma * dprev[i];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) t[i] -= oma * dprev[i];
             }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) X[i] = t[i];
         }
         __syncthreads();
         SDDP_TICK(11)

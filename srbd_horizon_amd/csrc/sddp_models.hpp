@@ -358,26 +358,31 @@ struct SrbdModel {
         core(c, r, o, w, cp, f, q);
         double L = input_cost(c, x, u, p, f, q);
         if (k >= 1) L += state_cost(c, x, p);
+        // every component of x+ is formed from values read BEFORE the first store: x and xn may be the same array (in-place
+        // rollout) or LDS columns the compiler cannot tell apart (then interleaved loads and stores would serialise)
         const double dt = c.dt;
+        double xp[NX];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            xn[XR + a] = x[XR + a] + dt * x[XRD + a];
-            xn[XRD + a] = x[XRD + a] + dt * q.rddot[a];
-            xn[XW + a] = x[XW + a] + dt * q.wdot[a];
+            xp[XR + a] = x[XR + a] + dt * x[XRD + a];
+            xp[XRD + a] = x[XRD + a] + dt * q.rddot[a];
+            xp[XW + a] = x[XW + a] + dt * q.wdot[a];
         }
         // odot = 1/2 [w;0] (x) o  (LOCAL_WORLD_ALIGNED, prb.py:107-108)
         double wxo[3];
         cross3(w, o, wxo);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) xn[XO + a] = o[a] + dt * 0.5 * (o[3] * w[a] + wxo[a]);
-        xn[XO + 3] = o[3] - dt * 0.5 * (w[0] * o[0] + w[1] * o[1] + w[2] * o[2]);
+        for (int a = 0; a < 3; ++a) xp[XO + a] = o[a] + dt * 0.5 * (o[3] * w[a] + wxo[a]);
+        xp[XO + 3] = o[3] - dt * 0.5 * (w[0] * o[0] + w[1] * o[1] + w[2] * o[2]);
         if (CS) {
 #pragma unroll
             for (int i = 0; i < 3 * NC; ++i) {
-                xn[XC + i] = x[XC + i] + dt * x[XCD + i];
-                xn[XCD + i] = x[XCD + i] + dt * u[6 * (i / 3) + (i % 3)];
+                xp[XC + i] = x[XC + i] + dt * x[XCD + i];
+                xp[XCD + i] = x[XCD + i] + dt * u[6 * (i / 3) + (i % 3)];
             }
         }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = xp[i];
         return L;
     }
 
@@ -873,12 +878,15 @@ struct LipModel {
         }
         if (k >= 1) L += state_cost(c, x, p);
         const double dt = c.dt;
+        double xp[NX];                                                            // read everything before the first store
 #pragma unroll
-        for (int i = 0; i < 15; ++i) xn[i] = x[i] + dt * x[15 + i];               // q += dt qdot  prb.py:323-328
+        for (int i = 0; i < 15; ++i) xp[i] = x[i] + dt * x[15 + i];               // q += dt qdot  prb.py:323-328
 #pragma unroll
-        for (int a = 0; a < 3; ++a) xn[XRD + a] = x[XRD + a] + dt * rddot[a];
+        for (int a = 0; a < 3; ++a) xp[XRD + a] = x[XRD + a] + dt * rddot[a];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) xn[XCD + i] = x[XCD + i] + dt * u[3 + i];
+        for (int i = 0; i < 12; ++i) xp[XCD + i] = x[XCD + i] + dt * u[3 + i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = xp[i];
         return L;
     }
 
