@@ -94,8 +94,8 @@ def cpu_baseline(N, B, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--batch", type=int, default=1024, help="MPC instances per GPU")
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
