@@ -1,0 +1,34 @@
+"""The byte accounting bench.py uses for the roofline: no GPU needed."""
+import importlib.util
+import os
+
+import numpy as np
+
+_spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+bench = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(bench)
+
+
+def test_algorithmic_bytes_match_the_survey_figures():
+    N, nx, nu, npar = 30, 13, 6, 19
+    one = bench.algorithmic_bytes(N, nx, nu, npar, np.array([1]), np.array([1]), 1)
+    assert one == 59024 + 14144                       # one iteration with one rollout + the I/O of one solve
+    it_only = bench.algorithmic_bytes(N, nx, nu, npar, np.array([2]), np.array([0]), 1) - bench.algorithmic_bytes(
+        N, nx, nu, npar, np.array([1]), np.array([0]), 1)
+    ro_only = bench.algorithmic_bytes(N, nx, nu, npar, np.array([0]), np.array([1]), 1) - bench.algorithmic_bytes(
+        N, nx, nu, npar, np.array([0]), np.array([0]), 1)
+    assert it_only == 8 * (1172 + 2520 + 583) and ro_only == 8 * 3103      # read knots, write gains, write accepted; rollout reads
+    # a batch is the sum of its instances
+    iters, ro = np.array([3, 5, 7]), np.array([4, 5, 9])
+    tot = bench.algorithmic_bytes(N, nx, nu, npar, iters, ro, 3)
+    assert tot == sum(bench.algorithmic_bytes(N, nx, nu, npar, np.array([i]), np.array([r]), 1) for i, r in zip(iters, ro))
+
+
+def test_bench_defaults_and_contract_fields():
+    src = open(bench.__file__).read()
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"', '"scaling"',
+                '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"bound"', '"achieved"', '"peak"',
+                '"frac"', '"traffic"', '"cores"', '"kind"', '"sample"'):
+        assert key in src, key
+    assert bench.HBM_PEAK_GBS == 8000.0
+    assert os.environ.get("GPU_MAX_HW_QUEUES") is not None          # importing bench.py sets the hardware-queue count
