@@ -30,7 +30,7 @@ __host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 
 template <class M>
 struct LdsMW {
-    static constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NI = NX + NE;
+    static constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NEV = M::NEV, NI = NX + NEV;   // product rows only
     // register-block shapes: W = (V~F~)^T in JW x LW blocks, Q in 3x3 lower-triangle blocks, Vxx in 2x2 lower-triangle blocks
     static constexpr int JW = 3;
     static constexpr int LW = (round_up(NZ, 3) / 3) * (round_up(NX, 3) / 3) <= kThreadsMW ? 3 : 4;
@@ -118,15 +118,15 @@ __device__ __forceinline__ void dot_block(const double* A, int lda, const double
 template <class M>
 __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
     using L = LdsMW<M>;
-    constexpr int NX = M::NX, NZ = M::NZ, NE = M::NE;
+    constexpr int NX = M::NX, NZ = M::NZ, NE = M::NE, NEV = M::NEV;
     for (int e = tid; e < L::TOTAL; e += kThreadsMW) s[e] = 0.0;    // also: zero record -> constant part of F below
     __syncthreads();
     for (int e = tid; e < NZ * NX; e += kThreadsMW) {
         const int j = e / NX, i = e % NX;
         s[L::FT + j * L::SI + i] = M::F_entry(c, s + L::REC, i, j);
     }
-    for (int e = tid; e < NZ * NE; e += kThreadsMW) {
-        const int j = e / NE, m = e % NE;
+    for (int e = tid; e < NZ * NEV; e += kThreadsMW) {
+        const int j = e / NEV, m = e % NEV;
         s[L::FT + j * L::SI + NX + m] = M::E_const(c, m, j);
     }
     int* ki = reinterpret_cast<int*>(s + L::KI);
@@ -149,13 +149,35 @@ __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
     __syncthreads();
 }
 
+// The constant extra rows (m >= NEV: node-independent weights) contribute sum_m lambda_m E[m][row] E[m][col] to Q: a constant
+// matrix.  Each thread keeps the 3x3 block it owns in the Q phase in registers for the whole kernel (call after sweep_tables_mw).
+template <class M>
+__device__ void mw_const_block(const DevConsts& c, const double* s, int tid, double (&qconst)[3][3]) {
+    using L = LdsMW<M>;
+    const int* ki = reinterpret_cast<const int*>(s + L::KI);
+    const int code = tid < L::NTRIQ ? ki[2 * L::SQ + tid] : 0;
+    const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double v = 0.0;
+            if (M::NEV < M::NE && tid < L::NTRIQ && a0 + i < M::NZ && b0 + j < M::NZ)
+                for (int m = M::NEV; m < M::NE; ++m) v += M::lam_stage(c, m) * M::E_const(c, m, a0 + i) * M::E_const(c, m, b0 + j);
+            qconst[i][j] = v;
+        }
+}
+
 // backward Riccati sweep on 4 waves; every thread gets the same return value and the same dV1 / G1 / G2 / qu_inf.
 template <class M>
 __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __restrict__ P, const double* __restrict__ dft,
                                   const double* __restrict__ rec, double* __restrict__ gains, double mu, double theta,
-                                  double* s, int tid, double& dV1, double& G1, double& G2, double& qu_inf SDDP_T_ARG) {
+                                  double* s, int tid, double& dV1, double& G1, double& G2, double& qu_inf,
+                                  const double (&qconst)[3][3] SDDP_T_ARG) {
+    // qconst: the constant extra rows' share of this thread's 3x3 Q block (mw_const_block, once per kernel)
     using L = LdsMW<M>;
-    constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NREC = M::NREC, NP = M::NP;
+    constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NEV = M::NEV, NREC = M::NREC, NP = M::NP;
+    static_assert(!M::CONST_ROWS_STATE_WEIGHTED, "constant rows must have node-independent weights");
     constexpr int SV = L::SV, SI = L::SI, SQ = L::SQ, SK = L::SK, NSTG = L::NSTG, RPW = L::RPW;
     constexpr int NCOL = NU + 1 + NX;
     constexpr int RS = (NSTG + kThreadsMW - 1) / kThreadsMW;
@@ -178,7 +200,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
     for (int e = tid; e < NX * NX; e += kThreadsMW) {
         const int a = e / NX, b = e % NX;
         double v = 0.0;
-        for (int m = 0; m < NE; ++m) v += s[L::LS + m] * s[L::FT + a * SI + NX + m] * s[L::FT + b * SI + NX + m];
+        for (int m = 0; m < NEV; ++m) v += s[L::LS + m] * s[L::FT + a * SI + NX + m] * s[L::FT + b * SI + NX + m];
         if (a == b) v += s[L::DS + a] + M::dparam(c, s + L::PK, ki[a], ki[SQ + a], 1.0, 0.0);
         s[L::VXX + a * SV + b] = v;
     }
@@ -234,8 +256,8 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 for (int ll = 0; ll < L::LW; ++ll)
                     if (j0 + jj < NZ && l0 + ll < NX) s[L::WT + (j0 + jj) * SI + l0 + ll] = acc[jj][ll];
         }
-        for (int e = tid; e < NZ * NE; e += kThreadsMW) {
-            const int j = e / NE, m = e % NE;
+        for (int e = tid; e < NZ * NEV; e += kThreadsMW) {
+            const int j = e / NEV, m = e % NEV;
             const double lam = state * s[L::LS + m] + s[L::LG + m];
             s[L::WT + j * SI + NX + m] = lam * s[L::FT + j * SI + NX + m];
         }
@@ -247,6 +269,12 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
             double acc[3][3] = {};
             dot_block<3, 3, SI>(s + L::FT + a0 * SI, SI, s + L::WT + b0 * SI, SI, acc);
+            if (NEV < NE) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][j] += qconst[i][j];
+            }
             if (a0 == b0) {   // diagonal block: add D, keep it exactly symmetric
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -565,6 +593,8 @@ __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
     double J = 0.0, gap = 0.0;
     SDDP_T_DECL
     sweep_tables_mw<M>(A.c, s, tid);
+    double qconst[3][3];
+    mw_const_block<M>(A.c, s, tid, qconst);
     // ---- starting point (cost and defect norm computed by wave 0, shared through CTL)
     if (o.initial_rollout) {
         J = rollout_mw<M, true>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, tid, s SDDP_T_PASS);
@@ -595,7 +625,7 @@ __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
             bool ok = true, stop = false, accepted = false;
             do {   // at most twice: a failed sweep / line search with the second-order term is redone without it
                 while (true) {
-                    ok = backward_sweep_mw<M>(A.c, N, P, dft, rec, gains, mu, theta, s, tid, dV1, G1, G2, qu_inf SDDP_T_PASS);
+                    ok = backward_sweep_mw<M>(A.c, N, P, dft, rec, gains, mu, theta, s, tid, dV1, G1, G2, qu_inf, qconst SDDP_T_PASS);
                     if (ok) break;
                     if (theta != 0.0) { theta = 0.0; continue; }
                     mu = fmax(mu, 0.0) * 10.0 + o.mu_min;
@@ -711,7 +741,9 @@ __global__ __launch_bounds__(kThreadsMW) void backward_kernel_mw(SolveArgs A) {
     }
     __syncthreads();
     double dV1, G1, G2, qu_inf;
-    const bool ok = backward_sweep_mw<M>(A.c, N, P, dft, rec, gains, A.mu, A.alpha, s, tid, dV1, G1, G2, qu_inf SDDP_T_PASS);
+    double qconst[3][3];
+    mw_const_block<M>(A.c, s, tid, qconst);
+    const bool ok = backward_sweep_mw<M>(A.c, N, P, dft, rec, gains, A.mu, A.alpha, s, tid, dV1, G1, G2, qu_inf, qconst SDDP_T_PASS);
     if (tid == 0) {
         double* sc = A.scal + size_t(b) * kScal;
         sc[0] = dV1; sc[1] = -0.5 * dV1; sc[2] = G1; sc[3] = G2; sc[4] = ok ? 1.0 : 0.0; sc[5] = A.mu; sc[6] = qu_inf; sc[7] = J;

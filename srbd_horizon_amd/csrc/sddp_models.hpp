@@ -691,12 +691,23 @@ struct SrbdModel {
     // Extra rows m >= NEV are constant (E_const) and their weights do not depend on the node: their contribution
     // sum_m lambda_m e_m e_m^T to Q is a constant matrix that the one-wave kernel adds instead of carrying the rows through the
     // tile products (srbd13: the three rddot rows -> product depth 20 -> 16).  NEV = NE: every row goes through the product.
-    static constexpr int NEV = CS ? NE : 3;
-    static constexpr bool CONST_ROWS_STATE_WEIGHTED = CS;      // rel_pos rows carry state-node weights (lam_state)
+    // Row order: first the NEV rows that must go through the tile products -- the variable wdot rows and, for the
+    // reference model, the rel_pos rows whose weight depends on the node (state nodes only) -- then the constant rows with
+    // node-independent weights (rddot, rel_vel).  erow() maps this order to the order of the definitions below.
+    static constexpr int NEV = CS ? 7 : 3;
+    static constexpr bool CONST_ROWS_STATE_WEIGHTED = false;
+    __device__ __forceinline__ static int erow(int m) {
+        if (!CS) return m;                       // wdot(0-2) rddot(3-5)
+        if (m < 3) return m;                     // wdot
+        if (m < 7) return m + 3;                 // rel_pos   (definition rows 6..9)
+        if (m < 10) return m - 4;                // rddot     (definition rows 3..5)
+        return m;                                // rel_vel   (definition rows 10..13)
+    }
     static constexpr int NVAR = 28 + 3 * NA;           // per-knot variable entries: quaternion blocks + A
 
     // constant entry of extra row m w.r.t. z_j (one-time table fill; variable wdot rows are 0 here)
-    __device__ static double E_const(const DevConsts& c, int m, int j) {
+    __device__ static double E_const(const DevConsts& c, int mrow, int j) {
+        const int m = erow(mrow);
         int cls, ci, ax;
         decode(j, cls, ci, ax);
         if (m < 3) return 0.0;
@@ -711,8 +722,12 @@ struct SrbdModel {
         if (cls != V_CD || ax != comp) return 0.0;
         return ci == 2 * pair ? 1.0 : (ci == 2 * pair + 1 ? -1.0 : 0.0);
     }
-    __device__ static double lam_state(const DevConsts& c, int m) { return (CS && m >= 6 && m < 10) ? 2 * c.w_rel : 0.0; }
-    __device__ static double lam_stage(const DevConsts& c, int m) {
+    __device__ static double lam_state(const DevConsts& c, int mrow) {
+        const int m = erow(mrow);
+        return (CS && m >= 6 && m < 10) ? 2 * c.w_rel : 0.0;
+    }
+    __device__ static double lam_stage(const DevConsts& c, int mrow) {
+        const int m = erow(mrow);
         if (m < 6) return 2 * c.gq;
         return (CS && m >= 10) ? 2 * c.w_pen : 0.0;
     }
@@ -1023,9 +1038,18 @@ struct LipModel {
     }
     // ---- branch-free expansion hooks (see SrbdModel): everything is constant, all couplings are extra rows
     static constexpr int NE = 16;   // rxy(2) zmp(3) rddot(3) rel_pos(4) rel_vel(4)
-    static constexpr int NEV = NE;
-    static constexpr bool CONST_ROWS_STATE_WEIGHTED = true;
-    __device__ static double E_const(const DevConsts& c, int m, int j) {
+    // product rows first: rxy(2) and rel_pos(4) carry state-node weights; then zmp(3) rddot(3) rel_vel(4): constant rows with
+    // node-independent weights, which enter Q as a constant matrix
+    static constexpr int NEV = 6;
+    static constexpr bool CONST_ROWS_STATE_WEIGHTED = false;
+    __device__ __forceinline__ static int erow(int m) {
+        if (m < 2) return m;                     // rxy
+        if (m < 6) return m + 6;                 // rel_pos   (definition rows 8..11)
+        if (m < 12) return m - 4;                // zmp, rddot (definition rows 2..7)
+        return m;                                // rel_vel   (definition rows 12..15)
+    }
+    __device__ static double E_const(const DevConsts& c, int mrow, int j) {
+        const int m = erow(mrow);
         int cls, ci, ax;
         decode(j, cls, ci, ax);
         if (m < 2) { if (ax != m) return 0.0; return cls == V_R ? 1.0 : (cls == V_C ? -0.25 : 0.0); }           // prb.py:391
@@ -1040,8 +1064,12 @@ struct LipModel {
         if (cls != V_CD || ax != comp) return 0.0;
         return ci == 2 * pair ? 1.0 : (ci == 2 * pair + 1 ? -1.0 : 0.0);
     }
-    __device__ static double lam_state(const DevConsts& c, int m) { return m < 2 ? 2 * c.w_rxy : ((m >= 8 && m < 12) ? 2 * c.w_rel : 0.0); }
-    __device__ static double lam_stage(const DevConsts& c, int m) {
+    __device__ static double lam_state(const DevConsts& c, int mrow) {
+        const int m = erow(mrow);
+        return m < 2 ? 2 * c.w_rxy : ((m >= 8 && m < 12) ? 2 * c.w_rel : 0.0);
+    }
+    __device__ static double lam_stage(const DevConsts& c, int mrow) {
+        const int m = erow(mrow);
         if (m < 2) return 0.0;
         if (m < 5) return 2 * c.w_zmp;
         if (m < 8) return 2 * c.gq;
