@@ -122,8 +122,12 @@ def main():
         raise SystemExit(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
-    if world > 1:
+    # SDDP_BENCH_FORCE_COLLECTIVE=1: rehearsal of the N > 1 step (record packing + all-gather on the 16 streams) with a
+    # one-rank RCCL communicator on a 1-GPU box; the printed line then carries "collective_rehearsal": true
+    collective = world > 1 or os.environ.get("SDDP_BENCH_FORCE_COLLECTIVE") == "1"
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -149,7 +153,7 @@ def main():
         e.use_torch_stream(st_)
         e.enable_timing(True)
         engs.append(e); streams.append(st_); views.append(e.fetch_device_views())
-        if world > 1:
+        if collective:
             sends.append(torch.empty((B, rec_words), dtype=torch.float64, device=dev))
             gathers.append(torch.empty((world * B, rec_words), dtype=torch.float64, device=dev))
     eng = engs[0]
@@ -165,7 +169,7 @@ def main():
             e.set_x_warmstart_device(d_xs)
             e.set_u_warmstart_device(d_us)
             e.solve_device(d_P)
-            if world > 1:
+            if collective:
                 x, u, sf, si = views[k]
                 send = sends[k]
                 send[:, :(N + 1) * nx] = x.reshape(B, -1)
@@ -175,7 +179,7 @@ def main():
                 dist.all_gather_into_tensor(gathers[k], send)  # RCCL over xGMI
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -194,7 +198,7 @@ def main():
         e.synchronize()
         e.kernel_time_stats(reset=True)
     elapsed = timed(args.steps)
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -218,7 +222,7 @@ def main():
                                "(alpha=1..1e-12, 40 candidates) rolled out per iteration",
                    "batch_per_gpu": B, "horizon_N": N, "solver_opts": opts, "algorithm": "MS-DDP, Gauss-Newton Hessians",
                    "batches_in_flight": S, "waves_per_simd": wps, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                   "collective": "all_gather(solution records) per step" if world > 1 else "none"},
+                   "collective": "all_gather(solution records) per step" if collective else "none"},
         "mean_iters": float(np.mean(iters)), "max_iters_hit_frac": float(np.mean(st["status"] == 1)),
         "converged_frac": float(np.mean(st["converged"] == 1)), "mean_rollouts": float(np.mean(rollouts)),
         "iterations_per_s": world * float(np.sum(iters)) * args.steps / elapsed,
@@ -296,9 +300,11 @@ def main():
             t_host.append(time.perf_counter() - t1)
         out["pcie_inclusive_solves_per_s"] = B / min(t_host)
         out["cpu_baseline"] = cpu_baseline(N, B)
+    if collective and world == 1:
+        out["collective_rehearsal"] = True
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 
