@@ -11,13 +11,13 @@ eng = DdpEngine(MODEL, N, B, opts=dict(max_iters=100, alpha_converge_threshold=1
 eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
 eng.enable_timing(True)
 x, u = eng.solve(batch["params"])
-sc = np.zeros((B, 16))
+sc = np.zeros((B, 24))
 fn = eng.lib.sddp_debug_read_scal; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p]
 assert fn(eng.h, sc.ctypes.data_as(C.c_void_p)) == 0
 it = eng.stats["iters"]; ro = eng.stats["rollouts"]
 names = ["derivs", "bw.stage", "bw.expand+vp", "bw.W=VxxF", "bw.Q=H+FtW", "bw.solve", "bw.Vupd+gains", "-", "rollout", "other"]
-names += ["ro.feedback", "ro.close-knot", "ro.step", "bw.Q.blocks(mw)", "bw.Q.qv+barrier(mw)"]
-tot = sc[:, :15].sum(axis=1)
+names += ["ro.feedback", "ro.close-knot", "ro.step", "bw.Q.blocks(mw)", "bw.Q.qv+barrier(mw)", "s15", "gj.load", "gj.owner", "gj.syncwait", "gj.update(+last)", "gj.publish", "s21","s22","s23"]
+tot = sc[:, :24].sum(axis=1)
 print("kernel ms", eng.last_kernel_ms(), "mean iters", it.mean(), "mean rollouts", ro.mean())
 print("cycles/iter (mean over instances): %.0f" % (tot / np.maximum(it, 1)).mean())
 for i, n in enumerate(names):

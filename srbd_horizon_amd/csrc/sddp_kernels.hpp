@@ -25,7 +25,7 @@ namespace sddp {
 
 constexpr int kWave = 64;
 constexpr int kSlots = 8;   // line-search candidates whose trajectories are kept per pass (one-wave kernel)
-constexpr int kScal = 16;  // doubles per instance in the scratch `scal` record (test kernels / diagnostic stamps)
+constexpr int kScal = 24;  // doubles per instance in the scratch `scal` record (test kernels / diagnostic stamps)
 
 // Diagnostic build only (-DSDDP_STAMPS): per-phase shader-cycle sums, written to `scal`; never in the shipped library.
 #ifdef SDDP_STAMPS

@@ -334,6 +334,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 qu_save[r] = v;
                 qu_acc = fmax(qu_acc, fabs(v));          // only lane NU's value is used
             }
+            SDDP_TICK(16)
             for (int blk = 0; blk < kWavesMW; ++blk) {
                 double* gt = s + L::GT + (blk & 1) * RPW * kWave;
                 if (wave == blk) {
@@ -355,7 +356,9 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                     for (int r = 0; r < RPW; ++r) gt[r * kWave + lane] = a[r];
                     if (lane == 0) s[L::CTL + 14 + (blk & 1)] = ok ? 1.0 : 0.0;
                 }
+                SDDP_TICK(17)
                 __syncthreads();
+                SDDP_TICK(18)
                 if (s[L::CTL + 14 + (blk & 1)] == 0.0) return false;
                 if (wave != blk) {
                     double pv[RPW][RPW];
@@ -373,6 +376,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                     }
                 }
             }
+            SDDP_TICK(19)
             // a = Quu^-1 * column ; publish kff and K^T (negated) ; dV1 += kff . Qu
             double dv = 0.0;
             // also the gains to HBM/L2 straight from the registers: kff (NU) then K (NU x NX) row-major; row i of K is one
@@ -391,6 +395,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             }
             dv_acc += dv;                                 // only lane NU's value is used
         }
+        SDDP_TICK(20)
         __syncthreads();
         SDDP_TICK(5)
         // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + Qux^T K (symmetric: lower triangle in 2x2 blocks, mirrored)
