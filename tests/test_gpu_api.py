@@ -116,6 +116,43 @@ def test_throughput_build_returns_the_same_results_as_the_latency_build():
     assert np.all(eng.stats["converged"] == 1)
 
 
+def test_batches_in_flight_on_separate_streams_equal_sequential_solves():
+    """The bench / fleet-server pattern: several handles, each on its own HIP stream, launched back to back with no host
+    synchronisation in between (sddp_set_stream, sddp_set_*_device, sddp_solve_device).  Every handle must return exactly what
+    a lone sequential solve of its batch returns: handles share nothing on the device."""
+    import torch
+    N, B, S = 30, 64, 4
+    opts = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3, waves_per_simd=2)
+    batches = [workload.make_batch("srbd13", N, 1000 * k + np.arange(B)) for k in range(S)]
+    ref = []
+    for bt in batches:
+        e = DdpEngine("srbd13", N, B, opts=opts)
+        e.set_initial_state(bt["x0"]); e.set_x_warmstart(bt["xs"]); e.set_u_warmstart(bt["us"])
+        x, u = e.solve(bt["params"])
+        ref.append((x.copy(), u.copy(), e.stats.copy()))
+    dev = torch.device("cuda", 0)
+    engs, streams, bufs = [], [], []
+    for bt in batches:
+        e = DdpEngine("srbd13", N, B, opts=opts)
+        st = torch.cuda.Stream()
+        e.use_torch_stream(st)
+        engs.append(e); streams.append(st)
+        bufs.append({k: torch.from_numpy(bt[k]).to(dev) for k in ("x0", "xs", "us", "params")})
+    torch.cuda.synchronize()
+    for rep in range(2):                                   # second round: the handles are reused while others still run
+        for e, st, d in zip(engs, streams, bufs):
+            with torch.cuda.stream(st):
+                e.set_initial_state_device(d["x0"]); e.set_x_warmstart_device(d["xs"]); e.set_u_warmstart_device(d["us"])
+                e.solve_device(d["params"])
+    torch.cuda.synchronize()
+    for e, (x0, u0, s0) in zip(engs, ref):
+        x, u, st = e.fetch()
+        np.testing.assert_array_equal(st["iters"], s0["iters"])
+        np.testing.assert_array_equal(x, x0)
+        np.testing.assert_array_equal(u, u0)
+        np.testing.assert_array_equal(st["cost"], s0["cost"])
+
+
 @pytest.mark.parametrize("model,ns", [("srbd13", 30), ("srbd37", 20), ("lip30", 20)])
 def test_device_resident_receding_horizon_equals_the_host_shift(model, ns):
     """sddp_set_params / sddp_advance / sddp_solve_resident: shifting the parameter tensor and the warm
