@@ -74,6 +74,75 @@ __global__ __launch_bounds__(1024) void bench(double* out, long long* cyc, int r
             for (int p = 0; p < 8; ++p)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i] = fma(lds[(r & 1) * 256 + (p * 8 + i) * 3], a[p], acc[i]);
+        } else if (MODE == 9) {   // 6x6 solve, every lane factors the (uniform) matrix itself: L D L^T + two substitutions, no lane traffic
+            double m[6][6], rd[6], x[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                x[i] = a[i] + acc[i];
+#pragma unroll
+                for (int j = 0; j <= i; ++j) m[i][j] = lds[(r & 1) * 64 + i * 6 + j] + (i == j ? 50.0 : 0.0);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                double cc[6];
+#pragma unroll
+                for (int j = 0; j < i; ++j) {
+                    double v = m[i][j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) v = fma(-cc[k], m[j][k], v);
+                    cc[j] = v;
+                }
+                double d = m[i][i];
+#pragma unroll
+                for (int j = 0; j < i; ++j) { m[i][j] = cc[j] * rd[j]; d = fma(-cc[j], m[i][j], d); }
+                double q = __builtin_amdgcn_rcp(d);
+                q = fma(fma(-d, q, 1.0), q, q);
+                rd[i] = fma(fma(-d, q, 1.0), q, q);
+            }
+#pragma unroll
+            for (int i = 1; i < 6; ++i)
+#pragma unroll
+                for (int k = 0; k < i; ++k) x[i] = fma(-m[i][k], x[k], x[i]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] *= rd[i];
+#pragma unroll
+            for (int i = 4; i >= 0; --i)
+#pragma unroll
+                for (int k = i + 1; k < 6; ++k) x[i] = fma(-m[k][i], x[k], x[i]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc[i] = x[i];
+        } else if (MODE == 10) {  // the same solve as a shared elimination: lane j owns column j, pivot column broadcast by v_readlane
+            double x[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] = lds[(r & 1) * 64 + i * 6 + (lane < 6 ? lane : 0)] + ((i == lane) ? 50.0 : 0.0) + (lane >= 6 ? a[i] + acc[i] : 0.0);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                double pv[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) pv[i] = readlane_d(x[i], p);
+                double q = __builtin_amdgcn_rcp(pv[p]);
+                q = fma(fma(-pv[p], q, 1.0), q, q);
+                q = fma(fma(-pv[p], q, 1.0), q, q);
+                const double t = x[p] * q;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) x[i] = (i == p) ? t : fma(-pv[i], t, x[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc[i] = x[i];
+        } else if (MODE == 11) {  // 64 dependent ops alternating v_mul_f64 / v_fma_f64 with a negated operand
+#pragma unroll
+            for (int p = 0; p < 32; ++p) {
+                const double t = acc[0] * a[p & 7];
+                acc[0] = fma(-t, a[(p + 3) & 7], a[(p + 1) & 7]);
+            }
+        } else if (MODE == 12) {  // 8 dependent v_rcp_f64 + Newton (5 instructions each)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const double d = acc[0] + a[p];
+                double q = __builtin_amdgcn_rcp(d);
+                q = fma(fma(-d, q, 1.0), q, q);
+                acc[0] = fma(fma(-d, q, 1.0), q, q);
+            }
         } else if (MODE == 5) {   // LDS round trip: write one value per lane, fence, broadcast-read 8 values
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
@@ -122,5 +191,9 @@ int main() {
     run<7>("64 ds_read_b64 per-lane slots + 64 fma", out, cyc);
     run<4>("8 x (readlane_d -> rcp -> mul -> fma)", out, cyc);
     run<5>("8 x (ds_write, fence, ds_read broadcast, fma)", out, cyc);
+    run<11>("64 dependent mul/fma alternating", out, cyc);
+    run<12>("8 dependent (add, rcp, 2 Newton steps)", out, cyc);
+    run<9>("6x6 solve: per-lane LDL^T, no lane traffic", out, cyc);
+    run<10>("6x6 solve: shared elimination, readlane pivots", out, cyc);
     return 0;
 }
