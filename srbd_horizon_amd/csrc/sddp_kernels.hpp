@@ -612,14 +612,27 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
 #pragma unroll
             for (int i = 0; i < NU; ++i) u[i] = ro[L::RO_U + i];
         } else {
-            double dx[NX];
+            // u = u_k + alpha kff + K (x - x_k).  The gain rows are fetched one row ahead of the row being used (two register rows,
+            // pinned row by row): left to the compiler every LDS read of the NU NX-long chain is issued just in time, one exposed
+            // round trip per two FMAs
+            double dx[NX], ub[NU], kf[NU], g[2][NX];
 #pragma unroll
             for (int j = 0; j < NX; ++j) dx[j] = x[j] - ro[L::RO_X + j];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                double acc = ro[L::RO_U + i] + alpha * ro[L::RO_G + i];
+            for (int i = 0; i < NU; ++i) { ub[i] = ro[L::RO_U + i]; kf[i] = ro[L::RO_G + i]; }
 #pragma unroll
-                for (int j = 0; j < NX; ++j) acc += ro[L::RO_G + NU + i * NX + j] * dx[j];
+            for (int j = 0; j < NX; ++j) g[0][j] = ro[L::RO_G + NU + j];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                if (i + 1 < NU) {
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) g[(i + 1) & 1][j] = ro[L::RO_G + NU + (i + 1) * NX + j];
+                }
+#pragma unroll
+                for (int j = 0; j < NX; ++j) asm volatile("" : "+v"(g[i & 1][j]));
+                double acc = ub[i] + alpha * kf[i];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) acc += g[i & 1][j] * dx[j];
                 u[i] = acc;
             }
         }
