@@ -115,6 +115,15 @@ __device__ __forceinline__ void dot_block(const double* A, int lda, const double
     for (int u = 0; u < REM; ++u) mac(u);
 }
 
+// Pins an array of loaded values: every element must be in its register here, so all the reads that produce them are issued
+// (in flight together) before the first use.  Left alone, the scheduler of these long straight-line phases issues each LDS read
+// just before its use: one exposed round trip per element (tools/isa_wait_batches.py shows them).
+template <int NN>
+__device__ __forceinline__ void pin_regs(double (&v)[NN]) {
+#pragma unroll
+    for (int i = 0; i < NN; ++i) asm volatile("" : "+v"(v[i]));
+}
+
 template <class M>
 __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
     using L = LdsMW<M>;
@@ -335,6 +344,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 qu_acc = fmax(qu_acc, fabs(v));          // only lane NU's value is used
             }
             SDDP_TICK(16)
+#pragma unroll
             for (int blk = 0; blk < kWavesMW; ++blk) {
                 double* gt = s + L::GT + (blk & 1) * RPW * kWave;
                 if (wave == blk) {
@@ -361,17 +371,19 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 SDDP_TICK(18)
                 if (s[L::CTL + 14 + (blk & 1)] == 0.0) return false;
                 if (wave != blk) {
-                    double pv[RPW][RPW];
+                    double pv[RPW][RPW], tv[RPW];
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) tv[r] = gt[r * kWave + lane];       // in flight behind the broadcasts below
 #pragma unroll
                     for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
                         for (int r = 0; r < RPW; ++r) pv[rr][r] = readlane_d(a[rr], min(blk * RPW + r, NU - 1));
+                    pin_regs(tv);
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) {
                         if (blk * RPW + r < NU) {
-                            const double t = gt[r * kWave + lane];
 #pragma unroll
-                            for (int rr = 0; rr < RPW; ++rr) a[rr] = fma(-pv[rr][r], t, a[rr]);
+                            for (int rr = 0; rr < RPW; ++rr) a[rr] = fma(-pv[rr][r], tv[r], a[rr]);
                         }
                     }
                 }
@@ -400,8 +412,13 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         SDDP_TICK(5)
         // ---- Vx = Qx + Qux^T kff ; Vxx = Qxx + Qux^T K (symmetric: lower triangle in 2x2 blocks, mirrored)
         if (wave == kLast && lane < NX) {
-            double acc = s[L::QV + lane];
-            for (int i = 0; i < NU; ++i) acc += s[L::Q + lane * SQ + NX + i] * s[L::KF + i];
+            double acc = s[L::QV + lane], qr[NU], kv[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { qr[i] = s[L::Q + lane * SQ + NX + i]; kv[i] = s[L::KF + i]; }
+            pin_regs(qr);
+            pin_regs(kv);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) acc += qr[i] * kv[i];
             s[L::VX + lane] = acc;
         }
         if (tid < L::NTRIV) {
@@ -508,8 +525,13 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
             for (int i = 0; i < NX; ++i) t[i] = Y[i];
             if (!(k == 0 || OPEN_LOOP)) {
                 const double* dprev = s + L::RO_S + ((k - 1) & 1) * L::SB_N + L::SB_D;
+                double dv[NX];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) t[i] -= oma * dprev[i];
+                for (int i = 0; i < NX; ++i) dv[i] = dprev[i];
+                pin_regs(t);                     // every read in flight before the first use (see pin_regs)
+                pin_regs(dv);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) t[i] -= oma * dv[i];
             }
 #pragma unroll
             for (int i = 0; i < NX; ++i) X[i] = t[i];
@@ -521,26 +543,47 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
         {
             double dx[NX];
             if (!OPEN_LOOP) {
+                double xk[NX];
 #pragma unroll
-                for (int j = 0; j < NX; ++j) dx[j] = X[j] - sb[L::SB_X + j];
+                for (int j = 0; j < NX; ++j) { dx[j] = X[j]; xk[j] = sb[L::SB_X + j]; }
+                pin_regs(dx);
+                pin_regs(xk);
+#pragma unroll
+                for (int j = 0; j < NX; ++j) dx[j] -= xk[j];
             }
+            // gain rows one row ahead of the row being used (two register rows), all reads of a row in flight together
+            constexpr int NXE = (NX + 1) & ~1;
+            double g[2][NXE], ub[UPW], kv[UPW];
+            auto load_row = [&](int r, double (&dst)[NXE]) {
+                const int i = wave * UPW + r < NU ? wave * UPW + r : NU - 1;
+                const double* row = kb + i * SG;
+#pragma unroll
+                for (int j = 0; j < NXE; j += 2) {
+                    const double2_t v = lds2(row + j);          // SG >= NXE: the pad column is finite, multiplied by nothing
+                    dst[j] = v.x;
+                    dst[j + 1] = v.y;
+                }
+            };
+#pragma unroll
+            for (int r = 0; r < UPW; ++r) {
+                const int i = wave * UPW + r < NU ? wave * UPW + r : NU - 1;
+                ub[r] = sb[L::SB_U + i];
+                kv[r] = OPEN_LOOP ? 0.0 : kf[i];
+            }
+            if (!OPEN_LOOP) load_row(0, g[0]);
 #pragma unroll
             for (int r = 0; r < UPW; ++r) {
                 const int i = wave * UPW + r;
-                if (i < NU) {
-                    double acc = sb[L::SB_U + i];
-                    if (!OPEN_LOOP) {
-                        acc = fma(alpha, kf[i], acc);
-                        const double* row = kb + i * SG;
+                double acc = ub[r];
+                if (!OPEN_LOOP) {
+                    if (r + 1 < UPW) load_row(r + 1, g[(r + 1) & 1]);
+                    pin_regs(g[r & 1]);
+                    acc = fma(alpha, kv[r], acc);
 #pragma unroll
-                        for (int j = 0; j + 1 < NX; j += 2) {
-                            const double2_t g = lds2(row + j);
-                            acc = fma(g.y, dx[j + 1], fma(g.x, dx[j], acc));
-                        }
-                        if (NX & 1) acc = fma(row[NX - 1], dx[NX - 1], acc);
-                    }
-                    U[i] = acc;
+                    for (int j = 0; j + 1 < NX; j += 2) acc = fma(g[r & 1][j + 1], dx[j + 1], fma(g[r & 1][j], dx[j], acc));
+                    if (NX & 1) acc = fma(g[r & 1][NX - 1], dx[NX - 1], acc);
                 }
+                if (i < NU) U[i] = acc;
             }
         }
         __syncthreads();
@@ -558,7 +601,13 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
         if (OPEN_LOOP) { for (int i = 0; i < NX; ++i) X[i] = Y[i]; }
         else {
             const double* dprev = s + L::RO_S + ((N - 1) & 1) * L::SB_N + L::SB_D;
-            for (int i = 0; i < NX; ++i) X[i] = Y[i] - oma * dprev[i];
+            double t[NX], dv[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { t[i] = Y[i]; dv[i] = dprev[i]; }
+            pin_regs(t);
+            pin_regs(dv);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) X[i] = t[i] - oma * dv[i];
         }
         J += M::term_cost(c, X, P + N * NP);
         if (lane == store_lane) {
