@@ -137,6 +137,9 @@ struct Lds {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2_t lds2(const double* p) { return *reinterpret_cast<const double2_t*>(p); }
+// Pins a loaded pair in its registers: the read that produces it has completed here, and (placed after the reads of later
+// stages in program order) those stay in flight behind it.  See DESIGN.md section 5, "exposed LDS round trips".
+__device__ __forceinline__ void pin2(double2_t& v) { asm volatile("" : "+v"(v)); }
 
 // -----------------------------------------------------------------------------------------------------------------
 // derivative phase: one lane per knot -> compact records in HBM/L2
@@ -360,14 +363,25 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             double a0[JB], a1[JB];
 #pragma unroll
             for (int jj = 0; jj < JB; ++jj) a0[jj] = a1[jj] = 0.0;
+            constexpr int NSW = NXP / 2, PFW = 2;       // operands two steps ahead, as in the Q phase below
+            double2_t v0[NSW], v1[NSW], ff[NSW][JB];
+            auto ldw = [&](int st) {
+                v0[st] = lds2(s + L::VXX + l0 * NXP + 2 * st); v1[st] = lds2(s + L::VXX + (l0 + 1) * NXP + 2 * st);
 #pragma unroll
-            for (int m = 0; m < NXP; m += 2) {
-                const double2_t v0 = lds2(s + L::VXX + l0 * NXP + m), v1 = lds2(s + L::VXX + (l0 + 1) * NXP + m);
+                for (int jj = 0; jj < JB; ++jj) ff[st][jj] = lds2(s + L::FT + (j0 + jj) * NIP + 2 * st);
+            };
+#pragma unroll
+            for (int st = 0; st < PFW && st < NSW; ++st) ldw(st);
+#pragma unroll
+            for (int st = 0; st < NSW; ++st) {
+                if (st + PFW < NSW) ldw(st + PFW);
+                pin2(v0[st]); pin2(v1[st]);
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) pin2(ff[st][jj]);
 #pragma unroll
                 for (int jj = 0; jj < JB; ++jj) {
-                    const double2_t f = lds2(s + L::FT + (j0 + jj) * NIP + m);
-                    a0[jj] = fma(v0.y, f.y, fma(v0.x, f.x, a0[jj]));
-                    a1[jj] = fma(v1.y, f.y, fma(v1.x, f.x, a1[jj]));
+                    a0[jj] = fma(v0[st].y, ff[st][jj].y, fma(v0[st].x, ff[st][jj].x, a0[jj]));
+                    a1[jj] = fma(v1[st].y, ff[st][jj].y, fma(v1[st].x, ff[st][jj].x, a1[jj]));
                 }
             }
 #pragma unroll
@@ -400,14 +414,24 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             const int code = codeq[q];
             const int a0 = 2 * (code >> 8), c0 = 2 * (code & 255);
             double q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+            // operands two steps ahead of the step being multiplied (three register stages, pinned stage by stage): the reads of
+            // the whole product stay in flight behind the FMAs instead of a round trip every other step
+            constexpr int NS = NIP / 2, PF = 2;
+            double2_t fa[NS], fb[NS], wa[NS], wb[NS];
+            auto ldq = [&](int st) {
+                fa[st] = lds2(s + L::FT + a0 * NIP + 2 * st); fb[st] = lds2(s + L::FT + (a0 + 1) * NIP + 2 * st);
+                wa[st] = lds2(s + L::WT + c0 * NIP + 2 * st); wb[st] = lds2(s + L::WT + (c0 + 1) * NIP + 2 * st);
+            };
 #pragma unroll
-            for (int l = 0; l < NIP; l += 2) {
-                const double2_t fa = lds2(s + L::FT + a0 * NIP + l), fb = lds2(s + L::FT + (a0 + 1) * NIP + l);
-                const double2_t wa = lds2(s + L::WT + c0 * NIP + l), wb = lds2(s + L::WT + (c0 + 1) * NIP + l);
-                q00 = fma(fa.y, wa.y, fma(fa.x, wa.x, q00));
-                q01 = fma(fa.y, wb.y, fma(fa.x, wb.x, q01));
-                q10 = fma(fb.y, wa.y, fma(fb.x, wa.x, q10));
-                q11 = fma(fb.y, wb.y, fma(fb.x, wb.x, q11));
+            for (int st = 0; st < PF && st < NS; ++st) ldq(st);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                if (st + PF < NS) ldq(st + PF);
+                pin2(fa[st]); pin2(fb[st]); pin2(wa[st]); pin2(wb[st]);
+                q00 = fma(fa[st].y, wa[st].y, fma(fa[st].x, wa[st].x, q00));
+                q01 = fma(fa[st].y, wb[st].y, fma(fa[st].x, wb[st].x, q01));
+                q10 = fma(fb[st].y, wa[st].y, fma(fb[st].x, wa[st].x, q10));
+                q11 = fma(fb[st].y, wb[st].y, fma(fb[st].x, wb[st].x, q11));
             }
             if (NEV < NE) { q00 += qconst[q][0]; q01 += qconst[q][1]; q10 += qconst[q][2]; q11 += qconst[q][3]; }
             if (a0 == c0) {   // diagonal block: add D, keep it exactly symmetric
