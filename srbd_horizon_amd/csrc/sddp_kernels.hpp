@@ -476,6 +476,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         SDDP_TICK(4)
         // ---- [k K] = -Quu^-1 [Qu Qux]: Gauss-Jordan, lane j owns column j of [Quu+mu I | Qu | Qux]
         double a[NU];
+        const double qx = s[L::QV + (lane > NU && lane < NCOL ? lane - NU - 1 : 0)];     // Qx of this lane's state column, for the Vx update
         {
             // column of Q this lane reads (any valid one for lane NU, which takes q instead; lanes >= NCOL are zeroed)
             const int qcol = lane < NU ? NX + lane : (lane > NU && lane < NCOL ? lane - NU - 1 : 0);
@@ -523,7 +524,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
 #pragma unroll
             for (int i = 0; i < NU; ++i) dot = fma(readlane_d(-a[i], NU), qu_save[i], dot);
             dV1 += readlane_d(dot, NU);
-            if (lane > NU && lane < NCOL) s[L::VX + lane - NU - 1] = s[L::QV + lane - NU - 1] + dot;
+            if (lane > NU && lane < NCOL) s[L::VX + lane - NU - 1] = qx + dot;
         }
         wave_sync();
         SDDP_TICK(5)
@@ -538,11 +539,19 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             const bool two = c0 + 1 <= a0;                          // the second column is in the lower triangle too
             const int c1 = two ? c0 + 1 : c0;
             double v0 = s[L::Q + a0 * SQ + c0], v1 = s[L::Q + a0 * SQ + c1];
+            double qa[NU], k0[NU], k1[NU];           // all operands in flight before the first FMA
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                const double qa = s[L::Q + a0 * SQ + NX + i];
-                v0 = fma(qa, s[L::KT + c0 * NUP + i], v0);
-                v1 = fma(qa, s[L::KT + c1 * NUP + i], v1);
+                qa[i] = s[L::Q + a0 * SQ + NX + i];
+                k0[i] = s[L::KT + c0 * NUP + i];
+                k1[i] = s[L::KT + c1 * NUP + i];
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { asm volatile("" : "+v"(qa[i])); asm volatile("" : "+v"(k0[i])); asm volatile("" : "+v"(k1[i])); }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                v0 = fma(qa[i], k0[i], v0);
+                v1 = fma(qa[i], k1[i], v1);
             }
             s[L::VXX + a0 * NXP + c0] = v0;
             if (c0 != a0) s[L::VXX + c0 * NXP + a0] = v0;
