@@ -287,9 +287,13 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (e == hipSuccess) e = alloc((void**)&h->rec, size_t(batch) * (N + 1) * d.nrec * D);
     if (e == hipSuccess) e = alloc((void**)&h->scal, size_t(batch) * kScal * D);
     if (e == hipSuccess) e = alloc((void**)&h->stats, size_t(batch) * sizeof(sddp_stats));
-    if (e == hipSuccess) e = hipMemset(h->stats, 0, size_t(batch) * sizeof(sddp_stats));
-    if (e == hipSuccess) e = hipMemset(h->dft, 0, size_t(batch) * N * d.nx * D);
-    if (e == hipSuccess) e = hipMemset(h->gains, 0, h->n_g() * D);
+    // on the handle's own stream, and complete before sddp_create returns: a null-stream hipMemset is asynchronous to the host
+    // and is NOT ordered with a non-blocking stream, so it could land in the middle of the first solve (seen once as a
+    // different iteration count on a 1-knot problem)
+    if (e == hipSuccess) e = hipMemsetAsync(h->stats, 0, size_t(batch) * sizeof(sddp_stats), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->dft, 0, size_t(batch) * N * d.nx * D, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->gains, 0, h->n_g() * D, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         g_create_error = std::string("sddp_create: ") + hipGetErrorString(e);
         sddp_destroy(h);

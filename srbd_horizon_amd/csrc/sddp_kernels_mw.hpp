@@ -543,25 +543,41 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
         {
             double dx[NX];
             if (!OPEN_LOOP) {
-                double xk[NX];
+                // x - x_k in chunks of CH entries, the next chunk's reads in flight behind the subtractions of this one
+                constexpr int CH = 10, NCH = (NX + CH - 1) / CH;
+                double xk[2][CH];
+                auto load_chunk = [&](int cI) {
 #pragma unroll
-                for (int j = 0; j < NX; ++j) { dx[j] = X[j]; xk[j] = sb[L::SB_X + j]; }
-                pin_regs(dx);
-                pin_regs(xk);
+                    for (int j = 0; j < CH; ++j)
+                        if (cI * CH + j < NX) { dx[cI * CH + j] = X[cI * CH + j]; xk[cI & 1][j] = sb[L::SB_X + cI * CH + j]; }
+                };
+                load_chunk(0);
 #pragma unroll
-                for (int j = 0; j < NX; ++j) dx[j] -= xk[j];
+                for (int cI = 0; cI < NCH; ++cI) {
+                    if (cI + 1 < NCH) load_chunk(cI + 1);
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+                        if (cI * CH + j < NX) { asm volatile("" : "+v"(dx[cI * CH + j])); asm volatile("" : "+v"(xk[cI & 1][j])); }
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+                        if (cI * CH + j < NX) dx[cI * CH + j] -= xk[cI & 1][j];
+                }
             }
-            // gain rows one row ahead of the row being used (two register rows), all reads of a row in flight together
-            constexpr int NXE = (NX + 1) & ~1;
-            double g[2][NXE], ub[UPW], kv[UPW];
-            auto load_row = [&](int r, double (&dst)[NXE]) {
+            // gain rows in units of HU entries, one unit ahead of the unit being used (two register units, pinned unit by unit):
+            // the reads stay in flight behind the FMAs without holding whole rows in registers
+            constexpr int NXE = (NX + 1) & ~1, HU = 10, NUNIT = (NXE + HU - 1) / HU, NT = UPW * NUNIT;
+            double gb[2][HU], ub[UPW], kv[UPW];
+            auto load_unit = [&](int t, double (&dst)[HU]) {
+                const int r = t / NUNIT, u = t % NUNIT;
                 const int i = wave * UPW + r < NU ? wave * UPW + r : NU - 1;
-                const double* row = kb + i * SG;
+                const double* row = kb + i * SG + u * HU;
 #pragma unroll
-                for (int j = 0; j < NXE; j += 2) {
-                    const double2_t v = lds2(row + j);          // SG >= NXE: the pad column is finite, multiplied by nothing
-                    dst[j] = v.x;
-                    dst[j + 1] = v.y;
+                for (int j = 0; j < HU; j += 2) {
+                    if (u * HU + j < NXE) {                      // SG >= NXE: the pad column is finite, multiplied by nothing
+                        const double2_t v = lds2(row + j);
+                        dst[j] = v.x;
+                        dst[j + 1] = v.y;
+                    }
                 }
             };
 #pragma unroll
@@ -570,20 +586,26 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
                 ub[r] = sb[L::SB_U + i];
                 kv[r] = OPEN_LOOP ? 0.0 : kf[i];
             }
-            if (!OPEN_LOOP) load_row(0, g[0]);
+            if (OPEN_LOOP) {
 #pragma unroll
-            for (int r = 0; r < UPW; ++r) {
-                const int i = wave * UPW + r;
-                double acc = ub[r];
-                if (!OPEN_LOOP) {
-                    if (r + 1 < UPW) load_row(r + 1, g[(r + 1) & 1]);
-                    pin_regs(g[r & 1]);
-                    acc = fma(alpha, kv[r], acc);
+                for (int r = 0; r < UPW; ++r)
+                    if (wave * UPW + r < NU) U[wave * UPW + r] = ub[r];
+            } else {
+                load_unit(0, gb[0]);
+                double acc = 0.0;
 #pragma unroll
-                    for (int j = 0; j + 1 < NX; j += 2) acc = fma(g[r & 1][j + 1], dx[j + 1], fma(g[r & 1][j], dx[j], acc));
-                    if (NX & 1) acc = fma(g[r & 1][NX - 1], dx[NX - 1], acc);
+                for (int t = 0; t < NT; ++t) {
+                    const int r = t / NUNIT, u = t % NUNIT;
+                    if (t + 1 < NT) load_unit(t + 1, gb[(t + 1) & 1]);
+#pragma unroll
+                    for (int j = 0; j < HU; ++j)
+                        if (u * HU + j < NXE) asm volatile("" : "+v"(gb[t & 1][j]));
+                    if (u == 0) acc = fma(alpha, kv[r], ub[r]);
+#pragma unroll
+                    for (int j = 0; j < HU; ++j)
+                        if (u * HU + j < NX) acc = fma(gb[t & 1][j], dx[u * HU + j], acc);
+                    if (u == NUNIT - 1 && wave * UPW + r < NU) U[wave * UPW + r] = acc;
                 }
-                if (i < NU) U[i] = acc;
             }
         }
         __syncthreads();
