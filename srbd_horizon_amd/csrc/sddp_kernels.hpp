@@ -339,11 +339,13 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         if (lane < NX) {
             double acc = 0.0;
             if (has_gap) {
+                double2_t vv[NXP / 2], dd[NXP / 2];
 #pragma unroll
-                for (int m = 0; m < NXP; m += 2) {
-                    const double2_t v = lds2(s + L::VXX + lane * NXP + m), d = lds2(s + L::DK + m);
-                    acc = fma(v.y, d.y, fma(v.x, d.x, acc));
-                }
+                for (int m = 0; m < NXP; m += 2) { vv[m / 2] = lds2(s + L::VXX + lane * NXP + m); dd[m / 2] = lds2(s + L::DK + m); }
+#pragma unroll
+                for (int m = 0; m < NXP / 2; ++m) { pin2(vv[m]); pin2(dd[m]); }
+#pragma unroll
+                for (int m = 0; m < NXP / 2; ++m) acc = fma(vv[m].y, dd[m].y, fma(vv[m].x, dd[m].x, acc));
             }
             const double d = s[L::DK + lane], vx = s[L::VX + lane];
             s[L::VP + lane] = vx + acc;

@@ -814,16 +814,20 @@ struct SrbdModel {
             const int blk = e / 9, a = (e % 9) / 3, b = e % 3;
             const int i = blk % NC;
             const bool isc = blk >= NC;
-            const double l0 = c.dt * vp[XW], l1 = c.dt * vp[XW + 1], l2 = c.dt * vp[XW + 2];
             const int yi = (a == b) ? 0 : 3 - a - b;                      // index of the y component in skew(y)[a][b], a != b
             const double* mi = rec + REC_MI + 3 * yi;
-            const double y = mi[0] * l0 + mi[1] * l1 + mi[2] * l2;
+            const int row = NX + uf(i) + a, col = isc ? XC + 3 * i + b : XR + b;
+            // every operand (and the two Q entries to update) requested before the first use: one LDS round trip, not five
+            double v0 = vp[XW], v1 = vp[XW + 1], v2 = vp[XW + 2], m0 = mi[0], m1 = mi[1], m2 = mi[2];
+            double q0 = Q[row * NZP + col], q1 = Q[col * NZP + row];
+            asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(m0), "+v"(m1), "+v"(m2), "+v"(q0), "+v"(q1));
+            const double l0 = c.dt * v0, l1 = c.dt * v1, l2 = c.dt * v2;
+            const double y = m0 * l0 + m1 * l1 + m2 * l2;
             const int d = (b - a + 3) % 3;                                // 2: +y , 1: -y , 0: diagonal (zero)
             const double sk = d == 2 ? y : (d == 1 ? -y : 0.0);
             const double val = theta * c.lever * (isc ? sk : -sk);
-            const int row = NX + uf(i) + a, col = isc ? XC + 3 * i + b : XR + b;
-            Q[row * NZP + col] += val;
-            Q[col * NZP + row] += val;
+            Q[row * NZP + col] = q0 + val;
+            Q[col * NZP + row] = q1 + val;
         }
     }
 
