@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDDP_ABI_VERSION 3
+#define SDDP_ABI_VERSION 4
 
 /* model ids */
 #define SDDP_MODEL_SRBD13 0 /* nx=13 nu=6  np=19 : BASELINE.json metric model (contacts are per-knot parameters) */
@@ -145,6 +145,11 @@ int  sddp_set_params(sddp_handle* h, const double* params /*[B][N+1][np]*/);
 int  sddp_advance(sddp_handle* h, const double* p_last /*[B][np]*/, const double* x0 /*[B][nx]*/);
 /* sddp_solve on the resident parameters */
 int  sddp_solve_resident(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats /*[B] or NULL*/);
+/* one model step per instance, x_next = f_k(x, u; p) with the handle's model and constants: the closed-loop simulator step
+ * of the examples (dsrbd_example.py:158-159: integrator EULER of the same dae, :76) through the solver's own device model
+ * code.  k = stage node whose parameters p are (0 <= k < N).  Host pointers; synchronous. */
+int  sddp_model_step(sddp_handle* h, const double* x /*[B][nx]*/, const double* u /*[B][nu]*/, const double* p /*[B][np]*/, int k,
+                     double* x_next /*[B][nx]*/);
 
 /* ---- building blocks exposed for parity tests (host pointers) ------------------------------------------------
  * The same device code the fused solve kernel uses, one phase at a time.

@@ -61,6 +61,7 @@ SYMBOLS = {
     "sddp_set_params": (C.c_int, [_vp, _vp]),
     "sddp_advance": (C.c_int, [_vp, _vp, _vp]),
     "sddp_solve_resident": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "sddp_model_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
     "sddp_create": (C.c_int, [_P(_vp), C.c_int, C.c_int, C.c_int, _P(SddpOptions), _P(SddpModelConsts)]),
     "sddp_destroy": (None, [_vp]),
     "sddp_last_error": (C.c_char_p, [_vp]),
@@ -124,7 +125,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.sddp_abi_version() != 3:
+    if lib.sddp_abi_version() != 4:
         raise RuntimeError("libsddp_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -60,6 +60,7 @@ struct sddp_handle {
     bool have_x0 = false, have_xws = false, have_uws = false, have_params = false;
     bool bar = false;               // friction-cone barrier build (consts.friction_barrier_weight > 0)
     double* tick_in = nullptr;      // [B][np + nx] staging of sddp_advance
+    double* step_buf = nullptr;     // [B][2 nx + nu + np] operands and result of sddp_model_step
 
     size_t n_x() const { return size_t(B) * (N + 1) * d.nx; }
     size_t n_u() const { return size_t(B) * N * d.nu; }
@@ -160,6 +161,13 @@ int launch_forward(sddp_handle* h, const SolveArgs& a) {
     constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(h->B), dim3(MW ? kThreadsMW : kWave), lds, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return SDDP_OK;
+}
+
+template <class M>
+int launch_model_step(sddp_handle* h, int k, const double* dx, const double* du, const double* dp, double* dxn) {
+    hipLaunchKernelGGL(model_step_kernel<M>, dim3((h->B + kWave - 1) / kWave), dim3(kWave), 0, h->stream, h->dc, h->B, k, dx, du, dp, dxn);
     HIP_TRY(h, hipGetLastError());
     return SDDP_OK;
 }
@@ -306,7 +314,7 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
 void sddp_destroy(sddp_handle* h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->xc, h->uc, h->tick_in, h->dft, h->gains, h->rec, h->scal, h->stats};
+    void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->xc, h->uc, h->tick_in, h->step_buf, h->dft, h->gains, h->rec, h->scal, h->stats};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -451,6 +459,22 @@ int sddp_solve_resident(sddp_handle* h, double* x_out, double* u_out, sddp_stats
     rc = sddp_synchronize(h);
     h->have_xws = true;
     return rc;
+}
+
+int sddp_model_step(sddp_handle* h, const double* x, const double* u, const double* p, int k, double* x_next) {
+    if (!h || !x || !u || !p || !x_next) return SDDP_ERR_ARG;
+    if (k < 0 || k >= h->N) return fail(h, SDDP_ERR_ARG, "sddp_model_step: k must be a stage node, 0 <= k < N");
+    const size_t B = size_t(h->B), nx = h->d.nx, nu = h->d.nu, np = h->d.np, D = sizeof(double);
+    if (!h->step_buf) HIP_TRY(h, hipMalloc((void**)&h->step_buf, B * (2 * nx + nu + np) * D));
+    double *dx = h->step_buf, *du = dx + B * nx, *dp = du + B * nu, *dxn = dp + B * np;
+    HIP_TRY(h, hipMemcpyAsync(dx, x, B * nx * D, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(du, u, B * nu * D, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dp, p, B * np * D, hipMemcpyHostToDevice, h->stream));
+    int rc = SDDP_OK;
+    DISPATCH(h, launch_model_step, h, k, dx, du, dp, dxn);
+    if (rc != SDDP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(x_next, dxn, B * nx * D, hipMemcpyDeviceToHost, h->stream));
+    return sddp_synchronize(h);
 }
 
 int sddp_is_converged(sddp_handle* h, int* flags) {

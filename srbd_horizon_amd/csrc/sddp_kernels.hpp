@@ -853,6 +853,29 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2))) void
 // -----------------------------------------------------------------------------------------------------------------
 // single-phase kernels for the parity tests (same device code as the fused kernel)
 // -----------------------------------------------------------------------------------------------------------------
+// one model step per instance, x+ = f(x, u, p_k) (ddp.py:228-230): the closed-loop simulator step of the examples
+// (dsrbd_example.py:158-159) through the same device model code as the solver.  One thread per instance.
+// -----------------------------------------------------------------------------------------------------------------
+template <class M>
+__global__ __launch_bounds__(kWave) void model_step_kernel(DevConsts c, int B, int k, const double* __restrict__ x,
+                                                           const double* __restrict__ u, const double* __restrict__ p,
+                                                           double* __restrict__ xn) {
+    constexpr int NX = M::NX, NU = M::NU, NP = M::NP;
+    const int b = blockIdx.x * kWave + threadIdx.x;
+    if (b >= B) return;
+    double xv[NX], uv[NU], pv[NP], xo[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xv[i] = x[size_t(b) * NX + i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) uv[i] = u[size_t(b) * NU + i];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pv[i] = p[size_t(b) * NP + i];
+    (void)M::step(c, xv, uv, pv, k, xo);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xn[size_t(b) * NX + i] = xo[i];
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // one wavefront per knot: lane 0 runs the scalar model code, all lanes expand the dense tiles
 template <class M>
 __global__ __launch_bounds__(kWave) void eval_knots_kernel(DevConsts c, int N, int nk, const int* __restrict__ kk,

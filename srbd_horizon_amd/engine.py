@@ -90,6 +90,13 @@ class DdpEngine:
         x = self._c(x0, (self.B, self.nx))
         self._chk(self.lib.sddp_advance(self.h, _lib.ptr(pl), _lib.ptr(x)))
 
+    def model_step(self, x, u, p, k: int = 0):
+        """x_next = f_k(x, u; p) per instance through the solver's device model code (simulator step, dsrbd_example.py:158-159)."""
+        xv = self._c(x, (self.B, self.nx)); uv = self._c(u, (self.B, self.nu)); pv = self._c(p, (self.B, self.np_))
+        out = np.empty((self.B, self.nx))
+        self._chk(self.lib.sddp_model_step(self.h, _lib.ptr(xv), _lib.ptr(uv), _lib.ptr(pv), int(k), _lib.ptr(out)))
+        return out
+
     def solve_resident(self):
         x = np.empty((self.B, self.N + 1, self.nx))
         u = np.empty((self.B, self.N, self.nu))

@@ -5,7 +5,7 @@ Per tick (dsrbd_example.py line numbers): setInitialState (:84) -> shift rdot_re
 one node (:102-106, one slice move per parameter) -> assign the commanded velocity at node ns (:109-124) -> wpg.set(action)
 (:126-131) -> solve, timed (:134-136: this is the "ms/MPC-tick" metric) -> simulate one Euler step with the first input
 and renormalise the quaternion (:158-160).  The closed-loop simulator step runs through the same HIP model code as the solver
-(`sddp_eval_knots`), so there is no second implementation of the dynamics on the host.
+(`sddp_model_step`), so there is no second implementation of the dynamics on the host.
 """
 from __future__ import annotations
 
@@ -15,7 +15,6 @@ import numpy as np
 
 from . import wpg as _wpg
 from .ddp import DDPSolver
-from .engine import eval_knots
 from .problem import Parameter
 from .prb import LIPProblem, SRBD13Problem, SRBDProblem
 
@@ -82,8 +81,7 @@ class MpcLoop:
         sol = self.solver.getSolutionDict()                                            # :137
         u0 = sol["u_opt"][:, 0]                                                        # :158
         p0 = s.prb.parameter_matrix()[0]
-        f, _, _, _, _ = eval_knots(self.model, ns, [0], self.state[None], u0[None], p0[None], consts=s.prb.model_consts)
-        self.state = f[0].copy()                                                       # :159 Euler step (same HIP model)
+        self.state = self.solver.ddp_solver.model_step(self.state[None], u0[None], p0[None], 0)[0]   # :159 Euler step (same HIP model)
         if self.model != "lip30":
             self.state[3:7] /= np.linalg.norm(self.state[3:7])                         # :160 (the LIP state has no quaternion)
         if self.warm_start == "shift":

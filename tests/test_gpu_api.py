@@ -153,6 +153,26 @@ def test_batches_in_flight_on_separate_streams_equal_sequential_solves():
         np.testing.assert_array_equal(st["cost"], s0["cost"])
 
 
+@pytest.mark.parametrize("model,N", [("srbd13", 30), ("srbd37", 20), ("lip30", 20)])
+def test_model_step_is_the_dynamics_of_the_knot_evaluation(model, N):
+    """sddp_model_step (the closed-loop simulator step, dsrbd_example.py:158-159) returns the same x+ as the f of
+    sddp_eval_knots, i.e. the solver's own Euler step (bit-exact: same device code), and validates its node argument."""
+    from srbd_horizon_amd.engine import eval_knots
+    B = 5
+    batch = workload.make_batch(model, N, np.arange(B))
+    eng = DdpEngine(model, N, B, consts=batch["consts"])
+    rng = np.random.default_rng(1)
+    x = batch["x0"] + 0.01 * rng.standard_normal(batch["x0"].shape)
+    u = batch["us"][:, 0] + 0.01 * rng.standard_normal(batch["us"][:, 0].shape)
+    for k in (0, N - 1):
+        p = batch["params"][:, k]
+        xn = eng.model_step(x, u, p, k)
+        f, _, _, _, _ = eval_knots(model, N, np.full(B, k), x, u, p, consts=batch["consts"])
+        np.testing.assert_array_equal(xn, f)
+    with pytest.raises(RuntimeError, match="stage node"):
+        eng.model_step(x, u, batch["params"][:, N], N)
+
+
 @pytest.mark.parametrize("model,ns", [("srbd13", 30), ("srbd37", 20), ("lip30", 20)])
 def test_device_resident_receding_horizon_equals_the_host_shift(model, ns):
     """sddp_set_params / sddp_advance / sddp_solve_resident: shifting the parameter tensor and the warm
