@@ -61,6 +61,8 @@ struct sddp_handle {
     bool bar = false;               // friction-cone barrier build (consts.friction_barrier_weight > 0)
     double* tick_in = nullptr;      // [B][np + nx] staging of sddp_advance
     double* step_buf = nullptr;     // [B][2 nx + nu + np] operands and result of sddp_model_step
+    void* pinned = nullptr;         // small batches: pinned host staging of x | u | stats, so the three result copies are truly asynchronous
+    size_t pinned_bytes = 0;
 
     size_t n_x() const { return size_t(B) * (N + 1) * d.nx; }
     size_t n_u() const { return size_t(B) * N * d.nu; }
@@ -317,6 +319,7 @@ void sddp_destroy(sddp_handle* h) {
     void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->xc, h->uc, h->tick_in, h->step_buf, h->dft, h->gains, h->rec, h->scal, h->stats};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
+    if (h->pinned) (void)hipHostFree(h->pinned);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -404,6 +407,32 @@ int sddp_synchronize(sddp_handle* h) {
     return SDDP_OK;
 }
 
+// results of the last solve to host pointers.  Small batches (one robot, a handful of robots) go through a pinned staging buffer:
+// copies into pageable memory block one by one, copies into pinned memory are enqueued and waited for once.
+static int fetch_results(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats) {
+    const size_t bx = h->n_x() * sizeof(double), bu = h->n_u() * sizeof(double), bs = size_t(h->B) * sizeof(sddp_stats);
+    if (!h->pinned && bx + bu + bs <= (size_t(256) << 10)) {
+        if (hipHostMalloc(&h->pinned, bx + bu + bs, hipHostMallocDefault) == hipSuccess) h->pinned_bytes = bx + bu + bs;
+        else { h->pinned = nullptr; (void)hipGetLastError(); }
+    }
+    if (h->pinned && h->pinned_bytes >= bx + bu + bs) {
+        char* st = static_cast<char*>(h->pinned);
+        HIP_TRY(h, hipMemcpyAsync(st, h->xs, bx, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(st + bx, h->us, bu, hipMemcpyDeviceToHost, h->stream));
+        if (stats) HIP_TRY(h, hipMemcpyAsync(st + bx + bu, h->stats, bs, hipMemcpyDeviceToHost, h->stream));
+        const int rc = sddp_synchronize(h);
+        if (rc != SDDP_OK) return rc;
+        std::memcpy(x_out, st, bx);
+        std::memcpy(u_out, st + bx, bu);
+        if (stats) std::memcpy(stats, st + bx + bu, bs);
+        return SDDP_OK;
+    }
+    HIP_TRY(h, hipMemcpyAsync(x_out, h->xs, bx, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(u_out, h->us, bu, hipMemcpyDeviceToHost, h->stream));
+    if (stats) HIP_TRY(h, hipMemcpyAsync(stats, h->stats, bs, hipMemcpyDeviceToHost, h->stream));
+    return sddp_synchronize(h);
+}
+
 int sddp_solve(sddp_handle* h, const double* params, double* x_out, double* u_out, sddp_stats* stats) {
     int rc = check_ready(h);
     if (rc != SDDP_OK) return rc;
@@ -411,10 +440,7 @@ int sddp_solve(sddp_handle* h, const double* params, double* x_out, double* u_ou
     HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     rc = sddp_solve_device(h, h->P);
     if (rc != SDDP_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(x_out, h->xs, h->n_x() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(u_out, h->us, h->n_u() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (stats) HIP_TRY(h, hipMemcpyAsync(stats, h->stats, size_t(h->B) * sizeof(sddp_stats), hipMemcpyDeviceToHost, h->stream));
-    rc = sddp_synchronize(h);
+    rc = fetch_results(h, x_out, u_out, stats);
     // the solution is the next warm start unless the caller overrides it (solver object persists across ticks,
     // dsrbd_example.py:59)
     h->have_xws = true;
@@ -453,10 +479,7 @@ int sddp_solve_resident(sddp_handle* h, double* x_out, double* u_out, sddp_stats
     if (!x_out || !u_out) return fail(h, SDDP_ERR_ARG, "NULL argument");
     rc = sddp_solve_device(h, h->P);
     if (rc != SDDP_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(x_out, h->xs, h->n_x() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(u_out, h->us, h->n_u() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (stats) HIP_TRY(h, hipMemcpyAsync(stats, h->stats, size_t(h->B) * sizeof(sddp_stats), hipMemcpyDeviceToHost, h->stream));
-    rc = sddp_synchronize(h);
+    rc = fetch_results(h, x_out, u_out, stats);
     h->have_xws = true;
     return rc;
 }
