@@ -61,6 +61,9 @@ struct sddp_handle {
     bool bar = false;               // friction-cone barrier build (consts.friction_barrier_weight > 0)
     double* tick_in = nullptr;      // [B][np + nx] staging of sddp_advance
     double* step_buf = nullptr;     // [B][2 nx + nu + np] operands and result of sddp_model_step
+    char* tick_pin = nullptr;       // two pinned images of tick_in (small batches)
+    int tick_flip = 0, tick_unsynced = 0;
+    double* step_pin = nullptr;     // pinned host image of step_buf (small batches)
     void* pinned = nullptr;         // small batches: pinned host staging of x | u | stats, so the three result copies are truly asynchronous
     size_t pinned_bytes = 0;
 
@@ -320,6 +323,8 @@ void sddp_destroy(sddp_handle* h) {
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->step_pin) (void)hipHostFree(h->step_pin);
+    if (h->tick_pin) (void)hipHostFree(h->tick_pin);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -395,6 +400,7 @@ int sddp_solve_device(sddp_handle* h, const double* d_params) {
 int sddp_synchronize(sddp_handle* h) {
     if (!h) return SDDP_ERR_ARG;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->tick_unsynced = 0;
     for (size_t i = 0; i < h->pending; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]) == hipSuccess) {
@@ -463,8 +469,25 @@ int sddp_advance(sddp_handle* h, const double* p_last, const double* x0) {
     if (!h->tick_in) HIP_TRY(h, hipMalloc((void**)&h->tick_in, size_t(h->B) * (h->d.np + h->d.nx) * sizeof(double)));
     double* d_pl = h->tick_in;
     double* d_x0 = h->tick_in + size_t(h->B) * h->d.np;
-    HIP_TRY(h, hipMemcpyAsync(d_pl, p_last, size_t(h->B) * h->d.np * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(d_x0, x0, size_t(h->B) * h->d.nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const size_t bp = size_t(h->B) * h->d.np * sizeof(double), bx0 = size_t(h->B) * h->d.nx * sizeof(double);
+    if (!h->tick_pin && bp + bx0 <= (size_t(256) << 10) && hipHostMalloc((void**)&h->tick_pin, 2 * (bp + bx0), hipHostMallocDefault) != hipSuccess) {
+        h->tick_pin = nullptr;
+        (void)hipGetLastError();
+    }
+    if (h->tick_pin) {   // one enqueued upload from pinned memory; two alternating images, so that the call need not wait for it
+        if (h->tick_unsynced >= 2) {   // both images may still be read by earlier uploads: wait (a solve in between does it anyway)
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            h->tick_unsynced = 0;
+        }
+        ++h->tick_unsynced;
+        char* hp = h->tick_pin + (h->tick_flip ^= 1) * (bp + bx0);
+        std::memcpy(hp, p_last, bp);
+        std::memcpy(hp + bp, x0, bx0);
+        HIP_TRY(h, hipMemcpyAsync(d_pl, hp, bp + bx0, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(d_pl, p_last, bp, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(d_x0, x0, bx0, hipMemcpyHostToDevice, h->stream));
+    }
     hipLaunchKernelGGL(advance_kernel, dim3(h->B), dim3(256), 0, h->stream, h->N, h->d.nx, h->d.nu, h->d.np, h->P, h->xs, h->us,
                        h->x0, d_pl, d_x0);
     HIP_TRY(h, hipGetLastError());
@@ -488,12 +511,30 @@ int sddp_model_step(sddp_handle* h, const double* x, const double* u, const doub
     if (!h || !x || !u || !p || !x_next) return SDDP_ERR_ARG;
     if (k < 0 || k >= h->N) return fail(h, SDDP_ERR_ARG, "sddp_model_step: k must be a stage node, 0 <= k < N");
     const size_t B = size_t(h->B), nx = h->d.nx, nu = h->d.nu, np = h->d.np, D = sizeof(double);
-    if (!h->step_buf) HIP_TRY(h, hipMalloc((void**)&h->step_buf, B * (2 * nx + nu + np) * D));
+    const size_t words = B * (2 * nx + nu + np);
+    if (!h->step_buf) HIP_TRY(h, hipMalloc((void**)&h->step_buf, words * D));
+    if (!h->step_pin && words * D <= (size_t(256) << 10) && hipHostMalloc((void**)&h->step_pin, words * D, hipHostMallocDefault) != hipSuccess) {
+        h->step_pin = nullptr;
+        (void)hipGetLastError();
+    }
     double *dx = h->step_buf, *du = dx + B * nx, *dp = du + B * nu, *dxn = dp + B * np;
+    int rc = SDDP_OK;
+    if (h->step_pin) {   // x | u | p packed in pinned memory: one enqueued upload, one enqueued download, one wait
+        double* hp = h->step_pin;
+        std::memcpy(hp, x, B * nx * D);
+        std::memcpy(hp + B * nx, u, B * nu * D);
+        std::memcpy(hp + B * (nx + nu), p, B * np * D);
+        HIP_TRY(h, hipMemcpyAsync(dx, hp, B * (nx + nu + np) * D, hipMemcpyHostToDevice, h->stream));
+        DISPATCH(h, launch_model_step, h, k, dx, du, dp, dxn);
+        if (rc != SDDP_OK) return rc;
+        HIP_TRY(h, hipMemcpyAsync(hp + B * (nx + nu + np), dxn, B * nx * D, hipMemcpyDeviceToHost, h->stream));
+        rc = sddp_synchronize(h);
+        if (rc == SDDP_OK) std::memcpy(x_next, hp + B * (nx + nu + np), B * nx * D);
+        return rc;
+    }
     HIP_TRY(h, hipMemcpyAsync(dx, x, B * nx * D, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(du, u, B * nu * D, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(dp, p, B * np * D, hipMemcpyHostToDevice, h->stream));
-    int rc = SDDP_OK;
     DISPATCH(h, launch_model_step, h, k, dx, du, dp, dxn);
     if (rc != SDDP_OK) return rc;
     HIP_TRY(h, hipMemcpyAsync(x_next, dxn, B * nx * D, hipMemcpyDeviceToHost, h->stream));
