@@ -279,6 +279,25 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             qconst[q][e] = v;
         }
     }
+    // diagonal blocks: what the diagonal term D of the lane's two diagonal entries needs is knot-invariant except for the knot's
+    // parameters, so it is read once per sweep (zeros on the lanes that own an off-diagonal block: the per-knot code below is
+    // then branch-free and its parameter reads are issued ahead of the tile product)
+    int dkind[PQ][2], dcidx[PQ][2];
+    double dsv[PQ][2], dgv[PQ][2];
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+        const int a0 = 2 * (codeq[q] >> 8), c0 = 2 * (codeq[q] & 255);
+        const bool on = lane + q * kWave < L::NTRIQ && a0 == c0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool one = on && a0 + e < NZ;
+            const int idx = one ? a0 + e : 0;
+            dkind[q][e] = one ? ki[idx] : 0;
+            dcidx[q][e] = one ? ki[NZP + idx] : 0;
+            dsv[q][e] = one ? s[L::DS + idx] : 0.0;
+            dgv[q][e] = one ? s[L::DG + idx] : 0.0;
+        }
+    }
     // ---- terminal node: Vx = lx_N, Vxx = lxx_N = diag(D_state) + Je^T Lambda_state Je  (ddp.py:216-226)
     {
         const double* rN = rec + size_t(N) * NREC;
@@ -416,6 +435,9 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             const int code = codeq[q];
             const int a0 = 2 * (code >> 8), c0 = 2 * (code & 255);
             double q00 = 0, q01 = 0, q10 = 0, q11 = 0;
+            // diagonal term of this knot (zero on off-diagonal blocks): parameter reads in flight behind the product's
+            const double dd0 = state * dsv[q][0] + dgv[q][0] + M::dparam(c, s + L::PK, dkind[q][0], dcidx[q][0], state, 1.0);
+            const double dd1 = state * dsv[q][1] + dgv[q][1] + M::dparam(c, s + L::PK, dkind[q][1], dcidx[q][1], state, 1.0);
             // operands two steps ahead of the step being multiplied (three register stages, pinned stage by stage): the reads of
             // the whole product stay in flight behind the FMAs instead of a round trip every other step
             constexpr int NS = NIP / 2, PF = 2;
@@ -436,13 +458,12 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
                 q11 = fma(fb[st].y, wb[st].y, fma(fb[st].x, wb[st].x, q11));
             }
             if (NEV < NE) { q00 += qconst[q][0]; q01 += qconst[q][1]; q10 += qconst[q][2]; q11 += qconst[q][3]; }
-            if (a0 == c0) {   // diagonal block: add D, keep it exactly symmetric
-                const double d0 = state * s[L::DS + a0] + s[L::DG + a0] + M::dparam(c, s + L::PK, ki[a0], ki[NZP + a0], state, 1.0);
-                const double d1 = state * s[L::DS + a0 + 1] + s[L::DG + a0 + 1] + M::dparam(c, s + L::PK, ki[a0 + 1], ki[NZP + a0 + 1], state, 1.0);
-                q00 += d0;
-                q11 += (a0 + 1 < NZ) ? d1 : 0.0;
+            {   // diagonal block: add D, keep it exactly symmetric (selects, no branch)
+                q00 += dd0;
+                q11 += dd1;
                 const double off = 0.5 * (q01 + q10);
-                q01 = q10 = off;
+                q01 = a0 == c0 ? off : q01;
+                q10 = a0 == c0 ? off : q10;
             }
             double2_t r0, r1;
             r0.x = q00; r0.y = q01; r1.x = q10; r1.y = q11;
