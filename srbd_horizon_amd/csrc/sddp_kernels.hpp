@@ -435,9 +435,6 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             const int code = codeq[q];
             const int a0 = 2 * (code >> 8), c0 = 2 * (code & 255);
             double q00 = 0, q01 = 0, q10 = 0, q11 = 0;
-            // diagonal term of this knot (zero on off-diagonal blocks): parameter reads in flight behind the product's
-            const double dd0 = state * dsv[q][0] + dgv[q][0] + M::dparam(c, s + L::PK, dkind[q][0], dcidx[q][0], state, 1.0);
-            const double dd1 = state * dsv[q][1] + dgv[q][1] + M::dparam(c, s + L::PK, dkind[q][1], dcidx[q][1], state, 1.0);
             // operands two steps ahead of the step being multiplied (three register stages, pinned stage by stage): the reads of
             // the whole product stay in flight behind the FMAs instead of a round trip every other step
             constexpr int NS = NIP / 2, PF = 2;
@@ -448,6 +445,9 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             };
 #pragma unroll
             for (int st = 0; st < PF && st < NS; ++st) ldq(st);
+            // diagonal term of this knot (zero on off-diagonal blocks): its parameter reads queue behind the first product operands
+            const double dd0 = state * dsv[q][0] + dgv[q][0] + M::dparam(c, s + L::PK, dkind[q][0], dcidx[q][0], state, 1.0);
+            const double dd1 = state * dsv[q][1] + dgv[q][1] + M::dparam(c, s + L::PK, dkind[q][1], dcidx[q][1], state, 1.0);
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
                 if (st + PF < NS) ldq(st + PF);

@@ -764,9 +764,12 @@ struct SrbdModel {
     }
     // parameter-dependent diagonal term of one knot (branch-free: all candidates evaluated, one selected)
     __device__ __forceinline__ static double dparam(const DevConsts& c, const double* p, int kind, int ci, double state, double stage) {
-        const double otg = p_otg(p);
-        const double n2 = p_oref(p, 0) * p_oref(p, 0) + p_oref(p, 1) * p_oref(p, 1) + p_oref(p, 2) * p_oref(p, 2) + p_oref(p, 3) * p_oref(p, 3);
-        const double sw = CS ? p[8 + 2 * ci] : p[17 + ci];
+        // every parameter read requested unconditionally and together (pinned): left alone the compiler sinks each read into the
+        // select that consumes it and the selects become branches with an exposed LDS round trip each
+        double otg = p_otg(p), o0 = p_oref(p, 0), o1 = p_oref(p, 1), o2 = p_oref(p, 2), o3 = p_oref(p, 3);
+        double sw = CS ? p[8 + 2 * ci] : p[17 + ci];
+        asm volatile("" : "+v"(otg), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(sw));
+        const double n2 = o0 * o0 + o1 * o1 + o2 * o2 + o3 * o3;
         const double v1 = state * 2 * otg * otg * n2;
         const double v2 = stage * 2 * c.w_sw * (1.0 - sw) * (1.0 - sw);
         const double v3 = stage * 2 * c.w_pen * sw * sw;
@@ -1104,7 +1107,8 @@ struct LipModel {
         return ci;
     }
     __device__ __forceinline__ static double dparam(const DevConsts& c, const double* p, int kind, int ci, double state, double stage) {
-        const double sw = p[4 + 2 * ci];
+        double sw = p[4 + 2 * ci];
+        asm volatile("" : "+v"(sw));                       // unconditional read (see SrbdModel::dparam)
         return kind == 3 ? stage * 2 * c.w_pen * sw * sw : 0.0;
     }
     __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int) {}
