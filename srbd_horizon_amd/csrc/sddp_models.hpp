@@ -782,27 +782,46 @@ struct SrbdModel {
     // WT != nullptr: also writes lam[m] * entry into the extra-row part of (V~ F~)^T (one-wave kernel)
     __device__ __forceinline__ static void expand_var(const DevConsts& c, const double* rec, double* FT, int NIP, int tid, int nthreads,
                                                       double* WT = nullptr, const double* lam = nullptr) {
-        for (int e = tid; e < NVAR; e += nthreads) {
-            int row, col, row2 = -1;
-            double val, raw = 0.0;
+        // two entries per thread and trip, both record reads (and weights) requested before the first store: the single-wave
+        // kernel (64 threads, NVAR > 64) needs two entries per lane and would otherwise sit out two LDS round trips in a row
+        auto decode_entry = [&](int e, int& row, int& col, int& row2, int& src) {
+            row2 = -1;
             if (e < 28) {
                 const int a = e / 7, t = e % 7;
                 row = XO + a;
                 const bool isq = t < 4;
                 col = isq ? XO + t : XW + (t - 4);
-                raw = rec[isq ? REC_JO + 4 * a + t : REC_JW + 3 * a + (t - 4)];
+                src = isq ? REC_JO + 4 * a + t : REC_JW + 3 * a + (t - 4);
             } else {
                 const int m = (e - 28) / NA, j = (e - 28) % NA;
                 row = XW + m;
                 row2 = NX + m;                                   // the same A entry is also extra row m (wdot residual)
                 col = zcol(j);
-                raw = rec[REC_A + m * NA + j];
+                src = REC_A + m * NA + j;
             }
-            val = (row == col ? 1.0 : 0.0) + c.dt * raw;
-            FT[col * NIP + row] = val;
-            if (row2 >= 0) {
-                FT[col * NIP + row2] = raw;
-                if (WT) WT[col * NIP + row2] = lam[row2 - NX] * raw;
+        };
+        for (int e0 = tid; e0 < NVAR; e0 += 2 * nthreads) {
+            const int e1 = e0 + nthreads;
+            const bool two = e1 < NVAR;
+            int row[2], col[2], row2[2], src[2];
+            decode_entry(e0, row[0], col[0], row2[0], src[0]);
+            decode_entry(two ? e1 : e0, row[1], col[1], row2[1], src[1]);
+            double raw[2], lm[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                raw[q] = rec[src[q]];
+                lm[q] = (WT && row2[q] >= 0) ? lam[row2[q] - NX] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { asm volatile("" : "+v"(raw[q])); asm volatile("" : "+v"(lm[q])); }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (q == 1 && !two) break;
+                FT[col[q] * NIP + row[q]] = (row[q] == col[q] ? 1.0 : 0.0) + c.dt * raw[q];
+                if (row2[q] >= 0) {
+                    FT[col[q] * NIP + row2[q]] = raw[q];
+                    if (WT) WT[col[q] * NIP + row2[q]] = lm[q] * raw[q];
+                }
             }
         }
     }
