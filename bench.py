@@ -8,15 +8,16 @@
 A "step" is one pass of the hot path over one batch of synthetic input: B = 1024 independent SRBD MPC instances per
 GPU (BASELINE configs[2]; 8 GPUs x 1024 = configs[3]), N = 30 knots, nx = 13, nu = 6, each solved from a cold
 warm start (x = x0 at every node, u = static input) to convergence with the reference example's solver options
-(dsrbd_example.py:55-58).  Inputs are resident in HBM before the timed region; a step = reset warm start (D2D) + the
-fused persistent solve kernel (+ the RCCL all-gather of the solution records when N > 1).
+(dsrbd_example.py:55-58).  Inputs are resident in HBM before the timed region; a step = reset of the batch's initial state and
+warm start (D2D) + its instances entering the engine's work queue (srbd_horizon_amd/fleet.py).  The queue is solved by ONE
+launch per `--queue-depth` steps (and at the end of the timed region): the resident wavefronts of the device (2 per SIMD =
+2048) pull instances until the queue is empty (+ the RCCL all-gather of the solution records when N > 1), on ONE stream.
 
-A batch ends with its slowest instance (93 DDP iterations; the mean is 16), so with ONE batch in flight the SIMDs of finished
-instances idle for most of the launch.  A fleet server keeps the GPU full by keeping several batches in flight: steps are
-issued round-robin on `--streams` (default 16) handles, each on its own HIP stream / hardware queue (GPU_MAX_HW_QUEUES is
-raised to 32 unless the environment sets it), with the kernel build that lets two instances share a SIMD
-(`waves_per_simd = 2`).  The strictly sequential figure (`--streams 1`, latency build) is reported beside it as
-`one_batch_in_flight_*`.  Weak scaling.
+Why a queue: a batch ends with its slowest instance (93 DDP iterations; the mean is 16) and 1024 instances do not fill 2048
+wavefront slots, so one launch per batch leaves most SIMD time idle.  The queue is ordered longest-previous-solve-first
+(sddp_options.queue_order, include/sddp.h): in this bench every step re-solves the same synthetic batch, so the order hint
+from the priming pass is exact -- the figure with plain index order is reported beside it (`index_order_solves_per_s`), and
+the strictly sequential one-batch-per-launch figure as `one_batch_in_flight_*`.  Weak scaling.
 
 Rank 0 prints ONE JSON line; `roofline` and `cpu_baseline` are defined in DESIGN.md ("Measurement").
 """
@@ -27,10 +28,6 @@ import sys
 import time
 
 import numpy as np
-
-# HIP maps streams onto this many hardware queues (default 4): batches on streams that share a queue would serialise.
-# Must be set before the HIP runtime initialises (i.e. before torch / the library are imported below).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -49,17 +46,22 @@ def algorithmic_bytes(N, nx, nu, npar, iters, rollouts, B):
     return float(np.sum(iters) * it + np.sum(rollouts) * ro + B * io)
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/<round>/pmc_summary.json,
-    collected with separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; gfx950 corrections applied there)."""
+def pmc_traffic(steps, depth):
+    """(HBM bytes per launch of the dominant kernel, source) from the committed rocprofv3 PMC passes of the latest round
+    (profiles/<round>/pmc_summary.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, gfx950
+    corrections applied there).  NOT a measurement of this run.  The passes are taken at a given launch size; the figure is
+    scaled to this run's average launch (instances per launch) since traffic is per instance."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")))
     if not files:
-        return None
+        return None, None
     try:
-        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+        d = json.load(open(files[-1]))
+        per_batch = float(d["traffic_bytes_per_launch"]) / float(d.get("batches_per_launch", 1))
+        launches = -(-steps // depth)
+        return per_batch * steps / launches, os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(N, B, budget_s=12.0):
@@ -96,18 +98,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=48)
-    ap.add_argument("--batch", type=int, default=1024, help="MPC instances per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="MPC instances per GPU and step")
     ap.add_argument("--horizon", type=int, default=30)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=16, help="batches in flight (handles on separate HIP streams)")
-    ap.add_argument("--waves-per-simd", type=int, default=0, help="kernel build: 1 latency, 2 throughput; 0 = 2 when --streams > 1")
-    ap.add_argument("--no-sequential", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the single-instance extras")
+    ap.add_argument("--queue-depth", type=int, default=64, help="steps (batches) one engine handle holds = most steps per launch")
+    ap.add_argument("--waves-per-simd", type=int, default=2, help="kernel build: 1 = one wavefront per SIMD, 2 = two")
+    ap.add_argument("--queue-order", type=int, default=1, help="1: longest previous solve first (sddp_options.queue_order), 0: index order")
+    ap.add_argument("--no-extras", action="store_true", help="skip the index-order and one-batch-in-flight measurements")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from srbd_horizon_amd import workload
     from srbd_horizon_amd.engine import DdpEngine
+    from srbd_horizon_amd.fleet import FleetQueue
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -122,8 +126,8 @@ def main():
         raise SystemExit(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
-    # SDDP_BENCH_FORCE_COLLECTIVE=1: rehearsal of the N > 1 step (record packing + all-gather on the 16 streams) with a
-    # one-rank RCCL communicator on a 1-GPU box; the printed line then carries "collective_rehearsal": true
+    # SDDP_BENCH_FORCE_COLLECTIVE=1: rehearsal of the N > 1 step (record packing + all-gather inside the flush) with a one-rank
+    # RCCL communicator on a 1-GPU box; the printed line then carries "collective_rehearsal": true
     collective = world > 1 or os.environ.get("SDDP_BENCH_FORCE_COLLECTIVE") == "1"
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -133,170 +137,128 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    N, B, S = args.horizon, args.batch, max(1, args.streams)
+    N, B = args.horizon, args.batch
+    Q = max(1, min(args.queue_depth, max(args.steps, 1)))
     nx, nu, npar = 13, 6, 19
     seeds = rank * B + np.arange(B)                        # instances are sharded contiguously across ranks
     batch = workload.make_batch("srbd13", N, seeds)
     opts = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsrbd_example.py:55-58
-    wps = args.waves_per_simd or (2 if S > 1 else 1)
+    wps = args.waves_per_simd
     d_x0 = torch.from_numpy(batch["x0"]).to(dev)
     d_xs = torch.from_numpy(batch["xs"]).to(dev)
     d_us = torch.from_numpy(batch["us"]).to(dev)
     d_P = torch.from_numpy(batch["params"]).to(dev)
-    rec_words = (N + 1) * nx + N * nu + 2                  # trajectory + (cost, iters)
-    # S handles on S HIP streams: S batches in flight.  A batch ends with its slowest instance, so with one batch in flight
-    # the SIMDs of finished instances idle; a serving loop keeps the next batch resident.
-    engs, streams, views, sends, gathers = [], [], [], [], []
-    for i in range(S):
-        e = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=wps))
-        st_ = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
-        e.use_torch_stream(st_)
-        e.enable_timing(True)
-        engs.append(e); streams.append(st_); views.append(e.fetch_device_views())
-        if collective:
-            sends.append(torch.empty((B, rec_words), dtype=torch.float64, device=dev))
-            gathers.append(torch.empty((world * B, rec_words), dtype=torch.float64, device=dev))
-    eng = engs[0]
+    d_P_all = d_P.repeat(Q, 1, 1).contiguous()             # the queue's parameter tensor, resident: every step's batch has the same plan
 
-    def step(i, engines=None):
-        if engines:                                             # strictly sequential extra measurement
-            k, e, st_ = 0, engines[0], streams[0]
-        else:
-            k = i % S
-            e, st_ = engs[k], streams[k]
-        with torch.cuda.stream(st_):
-            e.set_initial_state_device(d_x0)
-            e.set_x_warmstart_device(d_xs)
-            e.set_u_warmstart_device(d_us)
-            e.solve_device(d_P)
-            if collective:
-                x, u, sf, si = views[k]
-                send = sends[k]
-                send[:, :(N + 1) * nx] = x.reshape(B, -1)
-                send[:, (N + 1) * nx:(N + 1) * nx + N * nu] = u.reshape(B, -1)
-                send[:, -2] = sf[:, 0]                          # cost
-                send[:, -1] = si[:, 10].to(torch.float64)       # iters
-                dist.all_gather_into_tensor(gathers[k], send)  # RCCL over xGMI
+    def make_queue(order):
+        e = DdpEngine("srbd13", N, Q * B, opts=dict(opts, waves_per_simd=wps, queue_order=order))
+        e.use_torch_stream(torch.cuda.current_stream())
+        e.enable_timing(True)
+        return e, FleetQueue(e, d_P_all, B, Q, collective=collective)
+
+    eng, fleet = make_queue(args.queue_order)
 
     def barrier():
         if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n_steps, engines=None):
+    def run_steps(fl, n_steps):
+        for _ in range(n_steps):
+            fl.submit(d_x0, d_xs, d_us)                    # one step: one batch enters the queue (launch when the handle is full)
+        fl.flush()
+
+    def timed(fl, n_steps):
         barrier()
         t0 = time.perf_counter()
-        for i in range(n_steps):
-            step(i, engines)
+        run_steps(fl, n_steps)
         barrier()
         return time.perf_counter() - t0
 
-    for i in range(max(args.warmup, 0)):
-        step(i)
+    # warm-up: the W steps asked for, and at least one pass over every block of the handle the timed region will use, so that
+    # each of its instances has been solved once (code paths, caches, and the queue-order history)
+    priming = max(max(args.warmup, 0), min(Q, args.steps))
+    run_steps(fleet, priming)
     barrier()
-    for e in engs:
-        e.synchronize()
-        e.kernel_time_stats(reset=True)
-    elapsed = timed(args.steps)
+    eng.synchronize()
+    eng.kernel_time_stats(reset=True)
+    l0 = fleet.launches
+    elapsed = timed(fleet, args.steps)
     if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ksum = kcnt = 0
-    for e in engs:
-        e.synchronize()
-        sm, n = e.kernel_time_stats(reset=True)
-        ksum += sm; kcnt += n
+    eng.synchronize()
+    ksum, kcnt = eng.kernel_time_stats(reset=True)
+    launches = fleet.launches - l0
+    slots, last_grid, last_queued = eng.queue_info()
 
     x, u, st = eng.fetch()
+    st = st[:B]                                            # every block of the handle holds the same batch
     iters, rollouts = st["iters"].astype(np.int64), st["rollouts"].astype(np.int64)
     kms = ksum / max(kcnt, 1)
-    abytes = algorithmic_bytes(N, nx, nu, npar, iters, rollouts, B)
-    achieved = abytes / (kms * 1e-3) / 1e9
+    abytes_batch = algorithmic_bytes(N, nx, nu, npar, iters, rollouts, B)
+    abytes_launch = abytes_batch * args.steps / max(launches, 1)          # average launch of the timed region
+    achieved = abytes_launch / (kms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(args.steps, Q) if (B == 1024 and N == 30 and world == 1) else (None, None)
     out = {
         "metric": "SRBD-DDP solves/sec (N=30, nx=13, nu=6)", "value": world * B * args.steps / elapsed, "unit": "solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"SRBD N={N} nx=13 nu=6, batch={B} independent MPC instances per GPU "
+        "config": {"workload": f"SRBD N={N} nx=13 nu=6, batch={B} independent MPC instances per GPU and step "
                                "(BASELINE configs[2]; x8 GPUs = configs[3]), cold start, whole line-search ladder "
                                "(alpha=1..1e-12, 40 candidates) rolled out per iteration",
-                   "batch_per_gpu": B, "horizon_N": N, "solver_opts": opts, "algorithm": "MS-DDP, Gauss-Newton Hessians",
-                   "batches_in_flight": S, "waves_per_simd": wps, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                   "collective": "all_gather(solution records) per step" if collective else "none"},
-        "mean_iters": float(np.mean(iters)), "max_iters_hit_frac": float(np.mean(st["status"] == 1)),
-        "converged_frac": float(np.mean(st["converged"] == 1)), "mean_rollouts": float(np.mean(rollouts)),
+                   "batch_per_gpu": B, "horizon_N": N, "solver_opts": opts, "algorithm": "MS-DDP, Gauss-Newton Hessians + exact torque term",
+                   "queue_depth_steps": Q, "launches_timed": launches, "resident_slots": slots, "grid_last_launch": last_grid,
+                   "waves_per_simd": wps, "queue_order": "longest previous solve first" if args.queue_order else "index",
+                   "priming_steps": priming, "streams": 1,
+                   "collective": "all_gather(solution records) per launch" if collective else "none"},
+        "mean_iters": float(np.mean(iters)), "max_iters": int(np.max(iters)), "max_iters_hit_frac": float(np.mean(st["status"] == 1)),
+        "converged_frac": float(np.mean(st["converged"] == 1)), "line_search_stalled_frac": float(np.mean(st["status"] == 4)),
+        "mean_rollouts": float(np.mean(rollouts)),
         "iterations_per_s": world * float(np.sum(iters)) * args.steps / elapsed,
         # secondary: ~0.85 Mflop of fp64 per DDP iteration at (N, nx, nu) = (30, 13, 6) (dense backward
         # sweep 25.2 kflop/knot + model evaluation + one rollout), against the MI355X fp64 vector peak of 78.6 TFLOP/s
         "fp64_algorithmic_tflops": world * float(np.sum(iters)) * args.steps / elapsed * 0.85e6 * (N / 30.0) / 1e12,
         "fp64_vector_peak_frac": float(np.sum(iters)) * args.steps / elapsed * 0.85e6 * (N / 30.0) / 78.6e12,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic() if (B == 1024 and N == 30) else None, "kernel": ("solve_kernel_w2" if wps >= 2 else "solve_kernel") + "<SrbdModel<2,false>>", "kernel_ms": kms,
-                     "algorithmic_bytes_per_launch": abytes,
-                     "aggregate_achieved": world * B * args.steps / elapsed * (abytes / B) / 1e9,
-                     "note": "achieved = algorithmic bytes of one launch / its HIP-event duration (launches of different batches "
-                             "overlap, each lasts as long as its slowest instance); aggregate_achieved = solves/s x algorithmic "
-                             "bytes per solve, GB/s over all launches in flight"},
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": ("solve_kernel_w2" if wps >= 2 else "solve_kernel") + "<SrbdModel<2,false>>", "kernel_ms": kms,
+                     "launches": int(kcnt), "algorithmic_bytes_per_launch": abytes_launch,
+                     "note": "achieved = algorithmic bytes of the average timed launch (SURVEY 8(d) bytes per solve x the instances of "
+                             "the launch) / its HIP-event duration on the launch stream; one launch at a time on one stream; traffic is "
+                             "not measured in this run: it is read from the committed rocprofv3 PMC passes named in traffic_source"},
     }
-    if rank == 0 and world == 1 and S > 1 and not args.no_sequential:
-        # Extra: strictly one batch in flight (the next step starts after the previous one's slowest instance has finished),
-        # latency build of the kernel (full register file per instance)
+    if rank == 0 and world == 1 and not args.no_extras:
+        n_x = min(args.steps, Q)
+        if args.queue_order:
+            # the same queue in plain index order (no history hint), over one full handle
+            e_ix, f_ix = make_queue(0)
+            run_steps(f_ix, n_x)
+            el = timed(f_ix, n_x)
+            out["index_order_solves_per_s"] = B * n_x / el
+            del f_ix, e_ix
+        # strictly one batch per launch (the next step starts after the previous one's slowest instance has finished), the kernel
+        # build with the full register file per instance: the latency of one batch
         e_lat = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
-        e_lat.use_torch_stream(streams[0])
+        e_lat.use_torch_stream(torch.cuda.current_stream())
+        f_lat = FleetQueue(e_lat, d_P, B, 1)
         n1 = min(args.steps, 6)
-        timed(1, engines=[e_lat])
-        el1 = timed(n1, engines=[e_lat])
+        run_steps(f_lat, 1)
+        el1 = timed(f_lat, n1)
         out["one_batch_in_flight_solves_per_s"] = B * n1 / el1
         out["one_batch_in_flight_ms_per_step"] = 1e3 * el1 / n1
+        del f_lat, e_lat
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # ms / MPC tick, configs[1]: one instance, host-pointer call (PCIe included), cold start
-        e1 = DdpEngine("srbd13", N, 1, opts=opts)
-        b1 = workload.make_batch("srbd13", N, [0])
-        ticks = []
-        for _ in range(30):
-            e1.set_initial_state(b1["x0"]); e1.set_x_warmstart(b1["xs"]); e1.set_u_warmstart(b1["us"])
-            t1 = time.perf_counter()
-            e1.solve(b1["params"])
-            ticks.append(1e3 * (time.perf_counter() - t1))
-        out["ms_per_mpc_tick_b1"] = {"median": float(np.median(ticks[5:])), "p99": float(np.percentile(ticks[5:], 99)),
-                                     "iters": int(e1.stats["iters"][0]), "note": "B=1, seed 0, cold start, host-pointer sddp_solve (PCIe-inclusive)"}
-        # ms / MPC tick as SURVEY 8(d) defines it: receding-horizon loop (param shift + pack + solve + unpack + simulate),
-        # B = 1, warm-started from the previous tick, walking with a forward command; 20 warm-up + 200 timed ticks
-        from srbd_horizon_amd.mpc import MpcLoop
-        loop = MpcLoop("srbd13", N, warm_start="device")
-        tick_ms, solve_ms, its = [], [], []
-        for i in range(220):
-            t1 = time.perf_counter()
-            loop.tick("walking", (1.0, 0.0))
-            tick_ms.append(1e3 * (time.perf_counter() - t1))
-            its.append(int(loop.solver.stats["iters"]))
-        out["ms_per_mpc_tick"] = {"median": float(np.median(tick_ms[20:])), "p99": float(np.percentile(tick_ms[20:], 99)),
-                                  "solve_median": float(np.median(loop.solve_ms[20:])), "mean_iters": float(np.mean(its[20:])),
-                                  "note": "srbd13 receding-horizon loop (mpc.MpcLoop = dsrbd_example.py:82-185 without ROS), B=1, "
-                                          "N=30, walking forward, warm start = previous solution, 200 ticks after 20 warm-up; "
-                                          "tick = host scheduler + sddp_advance (device-side shift of parameters and warm start; last "
-                                          "parameter column and state over PCIe) + sddp_solve_resident + unpack + one simulator step"}
-        # the reference's own example loops (its real problem sizes, ns = 20, T = 1 s): dsrbd_example.py (srbd37) and
-        # dlip_example.py (lip30, configs[0]); 10 warm-up + 100 timed ticks each
-        out["ms_per_mpc_tick_reference_models"] = {}
-        for mname in ("srbd37", "lip30"):
-            lp = MpcLoop(mname, 20, warm_start="device")
-            tms, its = [], []
-            for i in range(110):
-                t1 = time.perf_counter()
-                lp.tick("walking", (1.0, 0.0))
-                tms.append(1e3 * (time.perf_counter() - t1))
-                its.append(int(lp.solver.stats["iters"]))
-            out["ms_per_mpc_tick_reference_models"][mname] = {
-                "median": float(np.median(tms[10:])), "p99": float(np.percentile(tms[10:], 99)),
-                "solve_median": float(np.median(lp.solve_ms[10:])), "mean_iters": float(np.mean(its[10:]))}
+        out.update(single_instance_extras(N, opts, workload, DdpEngine))
         # PCIe-inclusive batch rate (host-pointer C-ABI call: params in, x/u/stats out) -- reported, never `value`
-        eng.set_initial_state(batch["x0"])
+        e_h = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
+        e_h.set_initial_state(batch["x0"])
         t_host = []
         for _ in range(3):
-            eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+            e_h.set_x_warmstart(batch["xs"]); e_h.set_u_warmstart(batch["us"])
             t1 = time.perf_counter()
-            eng.solve(batch["params"])
+            e_h.solve(batch["params"])
             t_host.append(time.perf_counter() - t1)
         out["pcie_inclusive_solves_per_s"] = B / min(t_host)
         out["cpu_baseline"] = cpu_baseline(N, B)
@@ -306,6 +268,53 @@ def main():
         print(json.dumps(out))
     if collective:
         dist.destroy_process_group()
+
+
+def single_instance_extras(N, opts, workload, DdpEngine):
+    """ms / MPC tick figures (BASELINE metric, second half): B = 1."""
+    out = {}
+    # configs[1]: one instance, host-pointer call (PCIe included), cold start
+    e1 = DdpEngine("srbd13", N, 1, opts=opts)
+    b1 = workload.make_batch("srbd13", N, [0])
+    ticks = []
+    for _ in range(30):
+        e1.set_initial_state(b1["x0"]); e1.set_x_warmstart(b1["xs"]); e1.set_u_warmstart(b1["us"])
+        t1 = time.perf_counter()
+        e1.solve(b1["params"])
+        ticks.append(1e3 * (time.perf_counter() - t1))
+    out["ms_per_mpc_tick_b1"] = {"median": float(np.median(ticks[5:])), "p99": float(np.percentile(ticks[5:], 99)),
+                                 "iters": int(e1.stats["iters"][0]), "note": "B=1, seed 0, cold start, host-pointer sddp_solve (PCIe-inclusive)"}
+    # ms / MPC tick as SURVEY 8(d) defines it: receding-horizon loop (param shift + pack + solve + unpack + simulate),
+    # B = 1, warm-started from the previous tick, walking with a forward command; 20 warm-up + 200 timed ticks
+    from srbd_horizon_amd.mpc import MpcLoop
+    loop = MpcLoop("srbd13", N, warm_start="device")
+    tick_ms, its = [], []
+    for i in range(220):
+        t1 = time.perf_counter()
+        loop.tick("walking", (1.0, 0.0))
+        tick_ms.append(1e3 * (time.perf_counter() - t1))
+        its.append(int(loop.solver.stats["iters"]))
+    out["ms_per_mpc_tick"] = {"median": float(np.median(tick_ms[20:])), "p99": float(np.percentile(tick_ms[20:], 99)),
+                              "solve_median": float(np.median(loop.solve_ms[20:])), "mean_iters": float(np.mean(its[20:])),
+                              "note": "srbd13 receding-horizon loop (mpc.MpcLoop = dsrbd_example.py:82-185 without ROS), B=1, "
+                                      "N=30, walking forward, warm start = previous solution, 200 ticks after 20 warm-up; "
+                                      "tick = host scheduler + sddp_advance (device-side shift of parameters and warm start; last "
+                                      "parameter column and state over PCIe) + sddp_solve_resident + unpack + one simulator step"}
+    # the reference's own example loops (its real problem sizes, ns = 20, T = 1 s): dsrbd_example.py (srbd37) and
+    # dlip_example.py (lip30, configs[0]); 10 warm-up + 100 timed ticks each
+    out["ms_per_mpc_tick_reference_models"] = {}
+    for mname in ("srbd37", "lip30"):
+        lp = MpcLoop(mname, 20, warm_start="device")
+        tms, its = [], []
+        for i in range(110):
+            t1 = time.perf_counter()
+            lp.tick("walking", (1.0, 0.0))
+            tms.append(1e3 * (time.perf_counter() - t1))
+            its.append(int(lp.solver.stats["iters"]))
+        out["ms_per_mpc_tick_reference_models"][mname] = {
+            "median": float(np.median(tms[10:])), "p99": float(np.percentile(tms[10:], 99)),
+            "solve_median": float(np.median(lp.solve_ms[10:])), "mean_iters": float(np.mean(its[10:]))}
+    return out
 
 
 if __name__ == "__main__":

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDDP_ABI_VERSION 4
+#define SDDP_ABI_VERSION 5
 
 /* model ids */
 #define SDDP_MODEL_SRBD13 0 /* nx=13 nu=6  np=19 : BASELINE.json metric model (contacts are per-knot parameters) */
@@ -54,6 +54,12 @@ typedef struct sddp_options {
                                            half the register file, two instances resident per SIMD -- highest solves/s when
                                            several batches are in flight on separate streams.  Only the
                                            one-wavefront-per-instance kernel (srbd13) has both builds. */
+    int    queue_order;                 /* scheduling hint, no effect on results.  A solve launch runs on the workgroups that are
+                                           resident on the device at once ("slots": 256 CUs x 4 SIMDs x waves_per_simd for srbd13);
+                                           a batch with more instances than slots is a work queue the slots pull from.  1 (default):
+                                           the queue is ordered by the iteration count of each instance's PREVIOUS solve on this
+                                           handle, longest first (never-solved first): a launch ends with its slowest instance, so
+                                           the slow ones start first.  0: index order. */
 } sddp_options;
 
 /* replaces what the reference bakes into the CasADi graphs from the URDF and the rosparam server
@@ -89,7 +95,8 @@ typedef struct sddp_stats {
     double expected;   /* last expected reduction -(dV1+dV2)                */
     int    iters;      /* accepted iterations                               */
     int    converged;  /* 1/0                                               */
-    int    status;     /* 0 ok, 1 max_iters, 2 regularisation overflow, 3 non-finite */
+    int    status;     /* 0 ok, 1 max_iters, 2 regularisation overflow, 3 non-finite, 4 line search exhausted with the
+                          optimality conditions not met (converged = 0) */
     int    rollouts;   /* forward passes executed                           */
 } sddp_stats;
 
@@ -126,7 +133,18 @@ int  sddp_set_u_warmstart_device(sddp_handle* h, const double* d_u);
 /* asynchronous on the handle's stream; results stay in the handle's buffers (sddp_device_ptr) */
 int  sddp_solve_device(sddp_handle* h, const double* d_params);
 int  sddp_synchronize(sddp_handle* h);
-/* which: 0 xs [B][N+1][nx], 1 us [B][N][nu], 2 stats [B] (sddp_stats), 3 gains [B][N][nu*(nx+1)] */
+/* A handle as a queue of instances (a fleet server: batch = every robot it may hold).  Load the instances [first, first+count)
+ * (initial state, x / u warm start; device pointers to `count` instances, NULL = leave as is) and solve a contiguous range of
+ * the batch in ONE launch; d_params is the whole [B][N+1][np] tensor.  Each is asynchronous on the handle's stream.  The solve
+ * of an instance is bit-identical whatever range, order or slot it runs in. */
+int  sddp_load_range_device(sddp_handle* h, int first, int count, const double* d_x0, const double* d_x, const double* d_u);
+int  sddp_solve_range_device(sddp_handle* h, const double* d_params, int first, int count);
+/* slots: resident workgroups the work buffers exist for; grid and queue length (0: no queue) of the last solve launch */
+int  sddp_queue_info(sddp_handle* h, int* slots, int* last_grid, int* last_queued);
+/* results of the last device solve (x, u, stats of the whole batch) to host pointers; waits for the stream */
+int  sddp_fetch(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats /*[B] or NULL*/);
+/* which: 0 xs [B][N+1][nx], 1 us [B][N][nu], 2 stats [B] (sddp_stats), 3 gains [slots][N][nu*(nx+1)] (per slot: instance b's
+ * gains only while B <= slots), 4 x0 [B][nx], 5 params [B][N+1][np] (the resident tensor of sddp_set_params) */
 int  sddp_device_ptr(sddp_handle* h, int which, void** ptr, long long* bytes);
 /* average device time (ms) of the last `sddp_solve*` kernel launch measured with HIP events on the handle's stream */
 int  sddp_last_kernel_ms(sddp_handle* h, double* ms);

@@ -25,7 +25,7 @@ class SddpOptions(C.Structure):
     _fields_ = [("max_iters", C.c_int), ("alpha_0", C.c_double), ("alpha_converge_threshold", C.c_double),
                 ("line_search_decrease_factor", C.c_double), ("beta", C.c_double), ("cost_reduction_ths", C.c_double),
                 ("mu0", C.c_double), ("initial_rollout", C.c_int), ("gap_tol", C.c_double), ("mu_min", C.c_double),
-                ("mu_max", C.c_double), ("second_order", C.c_int), ("waves_per_simd", C.c_int)]
+                ("mu_max", C.c_double), ("second_order", C.c_int), ("waves_per_simd", C.c_int), ("queue_order", C.c_int)]
 
 
 class SddpModelConsts(C.Structure):
@@ -76,6 +76,10 @@ SYMBOLS = {
     "sddp_set_x_warmstart_device": (C.c_int, [_vp, _vp]),
     "sddp_set_u_warmstart_device": (C.c_int, [_vp, _vp]),
     "sddp_solve_device": (C.c_int, [_vp, _vp]),
+    "sddp_load_range_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "sddp_solve_range_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "sddp_queue_info": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
+    "sddp_fetch": (C.c_int, [_vp, _vp, _vp, _vp]),
     "sddp_synchronize": (C.c_int, [_vp]),
     "sddp_device_ptr": (C.c_int, [_vp, C.c_int, _P(_vp), _P(C.c_longlong)]),
     "sddp_last_kernel_ms": (C.c_int, [_vp, _P(C.c_double)]),
@@ -125,7 +129,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.sddp_abi_version() != 4:
+    if lib.sddp_abi_version() != 5:
         raise RuntimeError("libsddp_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -66,6 +67,17 @@ struct sddp_handle {
     double* step_pin = nullptr;     // pinned host image of step_buf (small batches)
     void* pinned = nullptr;         // small batches: pinned host staging of x | u | stats, so the three result copies are truly asynchronous
     size_t pinned_bytes = 0;
+    // work queue: the solve launch runs on `slots` resident workgroups that pull instances from a queue
+    int wslots = 0;                 // slots the work buffers (xn un xc uc dft gains rec) are allocated for = min(B, resident capacity)
+    int cus = 0;
+    int* qhead = nullptr;           // device queue head
+    int* order = nullptr;           // [B] queue order of the next launch
+    int* hist = nullptr;            // [B] iterations of each instance's previous solve (-1: none)
+    struct KInfo { const void* fn = nullptr; int slots = 0; };
+    KInfo kinfo[2];                 // per kernel build: dynamic-LDS attribute set, resident workgroups on this device
+    int last_grid = 0, last_queued = 0;
+    char* up_pin = nullptr;         // pinned ring for small host->device uploads of the setters (no wait per call)
+    size_t up_off = 0;
 
     size_t n_x() const { return size_t(B) * (N + 1) * d.nx; }
     size_t n_u() const { return size_t(B) * N * d.nu; }
@@ -92,6 +104,7 @@ SolveArgs make_args(sddp_handle* h, const double* d_params) {
     a.c = h->dc; a.o = h->opts; a.N = h->N; a.B = h->B;
     a.x0 = h->x0; a.P = d_params; a.xs = h->xs; a.us = h->us; a.xn = h->xn; a.un = h->un; a.xc = h->xc; a.uc = h->uc; a.dft = h->dft;
     a.gains = h->gains; a.rec = h->rec; a.stats = h->stats; a.scal = h->scal; a.alpha = 0.0; a.mu = 0.0;
+    a.first = 0; a.count = h->B; a.qhead = nullptr; a.order = nullptr; a.hist = h->hist;
     return a;
 }
 
@@ -123,13 +136,53 @@ template <class M> KernelFn pick_solve(int waves_per_simd) {
 template <class M> KernelFn pick_backward() { if constexpr (use_mw<M>()) return backward_kernel_mw<M>; else return backward_kernel<M>; }
 template <class M> KernelFn pick_forward() { if constexpr (use_mw<M>()) return forward_kernel_mw<M>; else return forward_kernel<M>; }
 
+constexpr size_t kUpRing = size_t(256) << 10;
+
+// resident workgroups of `kern` on this device (the queue's slot count) and its dynamic-LDS attribute, once per handle and build
 template <class M>
-int launch_solve(sddp_handle* h, const SolveArgs& a) {
+int kernel_slots(sddp_handle* h, KernelFn kern, int* slots) {
+    constexpr bool MW = use_mw<M>();
+    constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
+    constexpr int threads = MW ? kThreadsMW : kWave;
+    for (auto& k : h->kinfo)
+        if (k.fn == reinterpret_cast<const void*>(kern)) { *slots = k.slots; return SDDP_OK; }
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
+    if (!MW) per_cu = std::min(per_cu, 4 * (h->opts.waves_per_simd >= 2 ? 2 : 1));   // the two builds: 1 or 2 wavefronts per SIMD
+    if (const char* e = std::getenv("SDDP_SLOTS_PER_CU")) per_cu = std::atoi(e);     // diagnostic override
+    per_cu = std::max(1, std::min(per_cu, 32));
+    auto& k = h->kinfo[h->kinfo[0].fn ? 1 : 0];
+    k.fn = reinterpret_cast<const void*>(kern);
+    k.slots = per_cu * std::max(1, h->cus);
+    if (const char* e = std::getenv("SDDP_MAX_SLOTS")) k.slots = std::max(1, std::min(k.slots, std::atoi(e)));   // tests: a queue on few instances
+    *slots = k.slots;
+    return SDDP_OK;
+}
+
+// one launch over the instances [first, first + count): grid = resident slots, at most `count` and at most the slots the work
+// buffers exist for; more instances than slots -> work queue, in longest-previous-solve-first order when opts.queue_order is set
+template <class M>
+int launch_solve(sddp_handle* h, SolveArgs a, int first, int count) {
     constexpr bool MW = use_mw<M>();
     KernelFn kern = pick_solve<M>(h->opts.waves_per_simd);
     constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
     constexpr int threads = MW ? kThreadsMW : kWave;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int slots = 0;
+    int rc = kernel_slots<M>(h, kern, &slots);
+    if (rc != SDDP_OK) return rc;
+    const int grid = std::min(count, std::min(slots, h->wslots));
+    a.first = first; a.count = count;
+    if (count > grid) {
+        HIP_TRY(h, hipMemsetAsync(h->qhead, 0, sizeof(int), h->stream));
+        a.qhead = h->qhead;
+        if (h->opts.queue_order) {
+            hipLaunchKernelGGL(queue_order_kernel, dim3(1), dim3(1024), 0, h->stream, first, count, h->hist, h->order);
+            HIP_TRY(h, hipGetLastError());
+            a.order = h->order;
+        }
+    }
+    h->last_grid = grid; h->last_queued = count > grid ? count : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         while (h->ev.size() < 2 * (h->pending + 1)) {
@@ -141,13 +194,29 @@ int launch_solve(sddp_handle* h, const SolveArgs& a) {
         e1 = h->ev[2 * h->pending + 1];
         HIP_TRY(h, hipEventRecord(e0, h->stream));
     }
-    hipLaunchKernelGGL(kern, dim3(h->B), dim3(threads), lds, h->stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) {
         HIP_TRY(h, hipEventRecord(e1, h->stream));
         ++h->pending;
     }
     return SDDP_OK;
+}
+// resident capacity over the builds a handle may switch between (sddp_set_options): sizes the work buffers
+template <class M>
+int max_slots(sddp_handle* h, int* slots) {
+    if constexpr (use_mw<M>()) return kernel_slots<M>(h, pick_solve<M>(1), slots);
+    else {
+        const int keep = h->opts.waves_per_simd;
+        int s1 = 0, s2 = 0;
+        h->opts.waves_per_simd = 1;
+        int rc = kernel_slots<M>(h, pick_solve<M>(1), &s1);
+        h->opts.waves_per_simd = 2;
+        if (rc == SDDP_OK) rc = kernel_slots<M>(h, pick_solve<M>(2), &s2);
+        h->opts.waves_per_simd = keep;
+        *slots = std::max(s1, s2);
+        return rc;
+    }
 }
 template <class M>
 int launch_backward(sddp_handle* h, const SolveArgs& a) {
@@ -202,6 +271,13 @@ int validate_options(sddp_handle* h, const sddp_options& o) {
     if (!(o.alpha_converge_threshold > 0.0)) return fail(h, SDDP_ERR_ARG, "alpha_converge_threshold must be > 0");
     if (!(o.mu_min > 0.0)) return fail(h, SDDP_ERR_ARG, "mu_min must be > 0");
     if (o.waves_per_simd != 1 && o.waves_per_simd != 2) return fail(h, SDDP_ERR_ARG, "waves_per_simd must be 1 or 2");
+    // non-finite values would turn the regularisation loop or the line-search ladder of the persistent kernel into an endless loop
+    const double fin[] = {o.alpha_0, o.alpha_converge_threshold, o.line_search_decrease_factor, o.beta, o.cost_reduction_ths, o.mu0,
+                          o.gap_tol, o.mu_min, o.mu_max};
+    for (double v : fin)
+        if (!std::isfinite(v)) return fail(h, SDDP_ERR_ARG, "non-finite value in sddp_options");
+    if (!(o.mu_max > o.mu_min)) return fail(h, SDDP_ERR_ARG, "mu_max must be > mu_min");
+    if (o.queue_order != 0 && o.queue_order != 1) return fail(h, SDDP_ERR_ARG, "queue_order must be 0 or 1");
     return SDDP_OK;
 }
 
@@ -235,6 +311,7 @@ void sddp_default_options(sddp_options* o) {
     o->mu_max = 1e12;
     o->second_order = 1;
     o->waves_per_simd = 1;
+    o->queue_order = 1;
 }
 
 void sddp_default_consts(sddp_model_consts* c) {
@@ -283,29 +360,46 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
     hipError_t e = hipSuccess;
     const size_t D = sizeof(double);
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) h->cus = prop.multiProcessorCount;
+        else h->cus = 1;
+    }
+    // resident capacity of the solve kernel(s) on this device = number of queue slots; the work buffers exist per slot
+    int slots = 0;
+    DISPATCH(h, max_slots, h, &slots);
+    if (rc != SDDP_OK) { g_create_error = h->err; delete h; return rc; }
+    h->wslots = std::min(batch, slots);
+    const size_t W = size_t(h->wslots);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     h->own_stream = (e == hipSuccess);
     if (e == hipSuccess) e = alloc((void**)&h->x0, size_t(batch) * d.nx * D);
     if (e == hipSuccess) e = alloc((void**)&h->P, h->n_p() * D);
     if (e == hipSuccess) e = alloc((void**)&h->xs, h->n_x() * D);
     if (e == hipSuccess) e = alloc((void**)&h->us, h->n_u() * D);
-    if (e == hipSuccess) e = alloc((void**)&h->xn, h->n_x() * D);
-    if (e == hipSuccess) e = alloc((void**)&h->un, h->n_u() * D);
-    if (!model_uses_mw(model_id)) {   // one-wave kernel: two sets of kSlots line-search candidates per instance
-        if (e == hipSuccess) e = alloc((void**)&h->xc, h->n_x() * 2 * kSlots * D);
-        if (e == hipSuccess) e = alloc((void**)&h->uc, h->n_u() * 2 * kSlots * D);
+    if (e == hipSuccess) e = alloc((void**)&h->xn, W * (N + 1) * d.nx * D);
+    if (e == hipSuccess) e = alloc((void**)&h->un, W * N * d.nu * D);
+    if (!model_uses_mw(model_id)) {   // one-wave kernel: two sets of kSlots line-search candidates per slot
+        if (e == hipSuccess) e = alloc((void**)&h->xc, W * (N + 1) * d.nx * 2 * kSlots * D);
+        if (e == hipSuccess) e = alloc((void**)&h->uc, W * N * d.nu * 2 * kSlots * D);
     }
-    if (e == hipSuccess) e = alloc((void**)&h->dft, size_t(batch) * N * d.nx * D);
-    if (e == hipSuccess) e = alloc((void**)&h->gains, h->n_g() * D);
-    if (e == hipSuccess) e = alloc((void**)&h->rec, size_t(batch) * (N + 1) * d.nrec * D);
+    if (e == hipSuccess) e = alloc((void**)&h->dft, W * N * d.nx * D);
+    if (e == hipSuccess) e = alloc((void**)&h->gains, W * N * d.nu * (d.nx + 1) * D);
+    if (e == hipSuccess) e = alloc((void**)&h->rec, W * (N + 1) * d.nrec * D);
     if (e == hipSuccess) e = alloc((void**)&h->scal, size_t(batch) * kScal * D);
     if (e == hipSuccess) e = alloc((void**)&h->stats, size_t(batch) * sizeof(sddp_stats));
+    if (e == hipSuccess) e = alloc((void**)&h->qhead, sizeof(int));
+    if (e == hipSuccess) e = alloc((void**)&h->order, size_t(batch) * sizeof(int));
+    if (e == hipSuccess) e = alloc((void**)&h->hist, size_t(batch) * sizeof(int));
     // on the handle's own stream, and complete before sddp_create returns: a null-stream hipMemset is asynchronous to the host
     // and is NOT ordered with a non-blocking stream, so it could land in the middle of the first solve (seen once as a
     // different iteration count on a 1-knot problem)
     if (e == hipSuccess) e = hipMemsetAsync(h->stats, 0, size_t(batch) * sizeof(sddp_stats), h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->dft, 0, size_t(batch) * N * d.nx * D, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->gains, 0, h->n_g() * D, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->dft, 0, W * N * d.nx * D, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->gains, 0, W * N * d.nu * (d.nx + 1) * D, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->hist, 0xff, size_t(batch) * sizeof(int), h->stream);      // -1: never solved
+    if (e == hipSuccess) e = hipMemsetAsync(h->qhead, 0, sizeof(int), h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         g_create_error = std::string("sddp_create: ") + hipGetErrorString(e);
@@ -319,12 +413,14 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
 void sddp_destroy(sddp_handle* h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->xc, h->uc, h->tick_in, h->step_buf, h->dft, h->gains, h->rec, h->scal, h->stats};
+    void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->xc, h->uc, h->tick_in, h->step_buf, h->dft, h->gains, h->rec, h->scal, h->stats,
+                    h->qhead, h->order, h->hist};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->step_pin) (void)hipHostFree(h->step_pin);
     if (h->tick_pin) (void)hipHostFree(h->tick_pin);
+    if (h->up_pin) (void)hipHostFree(h->up_pin);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -340,67 +436,120 @@ int sddp_set_options(sddp_handle* h, const sddp_options* opts) {
 
 int sddp_set_stream(sddp_handle* h, void* s) {
     if (!h) return SDDP_ERR_ARG;
-    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->stream) (void)hipStreamSynchronize(h->stream);      // uploads enqueued from the pinned ring belong to the old stream
+    h->up_off = 0;
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = reinterpret_cast<hipStream_t>(s);
     h->own_stream = false;
+    return SDDP_OK;
+}
+
+// small host->device upload without a wait: the bytes are copied into a pinned ring and the transfer is enqueued on the handle's
+// stream (a copy from pageable memory would have to be waited for before the caller may reuse its buffer).  The ring is reused
+// from the start after a stream synchronisation; large uploads go directly and are waited for.
+static int upload(sddp_handle* h, void* dst, const void* src, size_t bytes) {
+    if (bytes <= kUpRing / 4) {
+        if (!h->up_pin && hipHostMalloc((void**)&h->up_pin, kUpRing, hipHostMallocDefault) != hipSuccess) {
+            h->up_pin = nullptr;
+            (void)hipGetLastError();
+        }
+        if (h->up_pin) {
+            const size_t need = (bytes + 63) & ~size_t(63);
+            if (h->up_off + need > kUpRing) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                h->up_off = 0;
+            }
+            std::memcpy(h->up_pin + h->up_off, src, bytes);
+            HIP_TRY(h, hipMemcpyAsync(dst, h->up_pin + h->up_off, bytes, hipMemcpyHostToDevice, h->stream));
+            h->up_off += need;
+            return SDDP_OK;
+        }
+    }
+    HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->up_off = 0;
     return SDDP_OK;
 }
 
 // ---- host-pointer setters -------------------------------------------------------------------------------------------
 int sddp_set_initial_state(sddp_handle* h, const double* x0) {
     if (!h || !x0) return SDDP_ERR_ARG;
-    HIP_TRY(h, hipMemcpyAsync(h->x0, x0, size_t(h->B) * h->d.nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->have_x0 = true;
-    return SDDP_OK;
+    const int rc = upload(h, h->x0, x0, size_t(h->B) * h->d.nx * sizeof(double));
+    if (rc == SDDP_OK) h->have_x0 = true;
+    return rc;
 }
 int sddp_set_x_warmstart(sddp_handle* h, const double* x) {
     if (!h || !x) return SDDP_ERR_ARG;
-    HIP_TRY(h, hipMemcpyAsync(h->xs, x, h->n_x() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->have_xws = true;
-    return SDDP_OK;
+    const int rc = upload(h, h->xs, x, h->n_x() * sizeof(double));
+    if (rc == SDDP_OK) h->have_xws = true;
+    return rc;
 }
 int sddp_set_u_warmstart(sddp_handle* h, const double* u) {
     if (!h || !u) return SDDP_ERR_ARG;
-    HIP_TRY(h, hipMemcpyAsync(h->us, u, h->n_u() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->have_uws = true;
-    return SDDP_OK;
+    const int rc = upload(h, h->us, u, h->n_u() * sizeof(double));
+    if (rc == SDDP_OK) h->have_uws = true;
+    return rc;
 }
 // ---- device-pointer setters -----------------------------------------------------------------------------------------
+int sddp_load_range_device(sddp_handle* h, int first, int count, const double* d_x0, const double* d_x, const double* d_u) {
+    if (!h) return SDDP_ERR_ARG;
+    if (first < 0 || count < 1 || first > h->B - count) return fail(h, SDDP_ERR_ARG, "instance range outside the batch");
+    const size_t D = sizeof(double), nx = h->d.nx, nu = h->d.nu, N = h->N;
+    if (d_x0) {
+        HIP_TRY(h, hipMemcpyAsync(h->x0 + size_t(first) * nx, d_x0, size_t(count) * nx * D, hipMemcpyDeviceToDevice, h->stream));
+        h->have_x0 = true;
+    }
+    if (d_x) {
+        HIP_TRY(h, hipMemcpyAsync(h->xs + size_t(first) * (N + 1) * nx, d_x, size_t(count) * (N + 1) * nx * D, hipMemcpyDeviceToDevice, h->stream));
+        h->have_xws = true;
+    }
+    if (d_u) {
+        HIP_TRY(h, hipMemcpyAsync(h->us + size_t(first) * N * nu, d_u, size_t(count) * N * nu * D, hipMemcpyDeviceToDevice, h->stream));
+        h->have_uws = true;
+    }
+    return SDDP_OK;
+}
 int sddp_set_initial_state_device(sddp_handle* h, const double* d) {
     if (!h || !d) return SDDP_ERR_ARG;
-    HIP_TRY(h, hipMemcpyAsync(h->x0, d, size_t(h->B) * h->d.nx * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    h->have_x0 = true;
-    return SDDP_OK;
+    return sddp_load_range_device(h, 0, h->B, d, nullptr, nullptr);
 }
 int sddp_set_x_warmstart_device(sddp_handle* h, const double* d) {
     if (!h || !d) return SDDP_ERR_ARG;
-    HIP_TRY(h, hipMemcpyAsync(h->xs, d, h->n_x() * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    h->have_xws = true;
-    return SDDP_OK;
+    return sddp_load_range_device(h, 0, h->B, nullptr, d, nullptr);
 }
 int sddp_set_u_warmstart_device(sddp_handle* h, const double* d) {
     if (!h || !d) return SDDP_ERR_ARG;
-    HIP_TRY(h, hipMemcpyAsync(h->us, d, h->n_u() * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    h->have_uws = true;
-    return SDDP_OK;
+    return sddp_load_range_device(h, 0, h->B, nullptr, nullptr, d);
 }
 
-int sddp_solve_device(sddp_handle* h, const double* d_params) {
+int sddp_solve_range_device(sddp_handle* h, const double* d_params, int first, int count) {
     int rc = check_ready(h);
     if (rc != SDDP_OK) return rc;
     if (!d_params) return fail(h, SDDP_ERR_ARG, "params is NULL");
+    if (first < 0 || count < 1 || first > h->B - count) return fail(h, SDDP_ERR_ARG, "instance range outside the batch");
     SolveArgs a = make_args(h, d_params);
-    DISPATCH(h, launch_solve, h, a);
+    DISPATCH(h, launch_solve, h, a, first, count);
     return rc;
+}
+
+int sddp_solve_device(sddp_handle* h, const double* d_params) {
+    if (!h) return SDDP_ERR_ARG;
+    return sddp_solve_range_device(h, d_params, 0, h->B);
+}
+
+int sddp_queue_info(sddp_handle* h, int* slots, int* last_grid, int* last_queued) {
+    if (!h) return SDDP_ERR_ARG;
+    if (slots) *slots = h->wslots;
+    if (last_grid) *last_grid = h->last_grid;
+    if (last_queued) *last_queued = h->last_queued;
+    return SDDP_OK;
 }
 
 int sddp_synchronize(sddp_handle* h) {
     if (!h) return SDDP_ERR_ARG;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->tick_unsynced = 0;
+    h->up_off = 0;
     for (size_t i = 0; i < h->pending; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]) == hipSuccess) {
@@ -416,6 +565,7 @@ int sddp_synchronize(sddp_handle* h) {
 // results of the last solve to host pointers.  Small batches (one robot, a handful of robots) go through a pinned staging buffer:
 // copies into pageable memory block one by one, copies into pinned memory are enqueued and waited for once.
 static int fetch_results(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats) {
+    if (!x_out || !u_out) return fail(h, SDDP_ERR_ARG, "NULL argument");
     const size_t bx = h->n_x() * sizeof(double), bu = h->n_u() * sizeof(double), bs = size_t(h->B) * sizeof(sddp_stats);
     if (!h->pinned && bx + bu + bs <= (size_t(256) << 10)) {
         if (hipHostMalloc(&h->pinned, bx + bu + bs, hipHostMallocDefault) == hipSuccess) h->pinned_bytes = bx + bu + bs;
@@ -439,11 +589,17 @@ static int fetch_results(sddp_handle* h, double* x_out, double* u_out, sddp_stat
     return sddp_synchronize(h);
 }
 
+int sddp_fetch(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats) {
+    if (!h) return SDDP_ERR_ARG;
+    return fetch_results(h, x_out, u_out, stats);
+}
+
 int sddp_solve(sddp_handle* h, const double* params, double* x_out, double* u_out, sddp_stats* stats) {
     int rc = check_ready(h);
     if (rc != SDDP_OK) return rc;
     if (!params || !x_out || !u_out) return fail(h, SDDP_ERR_ARG, "NULL argument");
-    HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = upload(h, h->P, params, h->n_p() * sizeof(double));
+    if (rc != SDDP_OK) return rc;
     rc = sddp_solve_device(h, h->P);
     if (rc != SDDP_OK) return rc;
     rc = fetch_results(h, x_out, u_out, stats);
@@ -455,10 +611,9 @@ int sddp_solve(sddp_handle* h, const double* params, double* x_out, double* u_ou
 
 int sddp_set_params(sddp_handle* h, const double* params) {
     if (!h || !params) return SDDP_ERR_ARG;
-    HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->have_params = true;
-    return SDDP_OK;
+    const int rc = upload(h, h->P, params, h->n_p() * sizeof(double));
+    if (rc == SDDP_OK) h->have_params = true;
+    return rc;
 }
 
 int sddp_advance(sddp_handle* h, const double* p_last, const double* x0) {
@@ -557,7 +712,9 @@ int sddp_device_ptr(sddp_handle* h, int which, void** ptr, long long* bytes) {
         case 0: *ptr = h->xs; n = (long long)(h->n_x() * sizeof(double)); break;
         case 1: *ptr = h->us; n = (long long)(h->n_u() * sizeof(double)); break;
         case 2: *ptr = h->stats; n = (long long)(size_t(h->B) * sizeof(sddp_stats)); break;
-        case 3: *ptr = h->gains; n = (long long)(h->n_g() * sizeof(double)); break;
+        case 3: *ptr = h->gains; n = (long long)(size_t(h->wslots) * h->N * h->d.nu * (h->d.nx + 1) * sizeof(double)); break;   // per slot
+        case 4: *ptr = h->x0; n = (long long)(size_t(h->B) * h->d.nx * sizeof(double)); break;
+        case 5: *ptr = h->P; n = (long long)(h->n_p() * sizeof(double)); break;
         default: return fail(h, SDDP_ERR_ARG, "unknown buffer id");
     }
     if (bytes) *bytes = n;
@@ -640,6 +797,7 @@ int sddp_backward(sddp_handle* h, const double* params, double mu, double* gains
     int rc = check_ready(h);
     if (rc != SDDP_OK) return rc;
     if (!params) return fail(h, SDDP_ERR_ARG, "params is NULL");
+    if (h->B > h->wslots) return fail(h, SDDP_ERR_ARG, "phase-level entry points need batch <= resident slots (sddp_queue_info)");
     HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     SolveArgs a = make_args(h, h->P);
     a.mu = mu;
@@ -660,6 +818,7 @@ int sddp_forward(sddp_handle* h, const double* params, double alpha, double* x_o
     int rc = check_ready(h);
     if (rc != SDDP_OK) return rc;
     if (!params) return fail(h, SDDP_ERR_ARG, "params is NULL");
+    if (h->B > h->wslots) return fail(h, SDDP_ERR_ARG, "phase-level entry points need batch <= resident slots (sddp_queue_info)");
     HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     SolveArgs a = make_args(h, h->P);
     a.alpha = alpha;

@@ -59,6 +59,15 @@ struct SolveArgs {
     double* scal;       // [B][kScal] (test kernels / diagnostic stamps)
     double alpha;       // forward test kernel only
     double mu;          // backward test kernel only
+    // work queue (solve kernels).  The launch covers `count` instances; the grid is the resident workgroups ("slots"), at most
+    // `count` of them.  qhead == nullptr: workgroup w solves instance first + w (grid == count).  Otherwise every workgroup
+    // takes queue positions i = atomicAdd(qhead, 1) until i >= count and solves instance order[i] (order == nullptr:
+    // first + i).  The work buffers xn/un/xc/uc/dft/gains/rec are per SLOT (indexed by blockIdx.x), x0/P/xs/us/stats/scal/hist
+    // per instance.
+    int first, count;
+    int* qhead;
+    const int* order;   // [count] absolute instance indices, or nullptr
+    int* hist;          // [B] iterations of the last solve of each instance (-1: never solved): the queue-order key
 };
 
 // Hand-off between phases of a ONE-WAVEFRONT workgroup.  LDS (and global) accesses of one wave are performed in issue order, so a
@@ -720,10 +729,9 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
 // fused persistent solve: one wavefront per MPC instance, all iterations in one launch (replaces ddp.py:101)
 // -----------------------------------------------------------------------------------------------------------------
 template <class M>
-__device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
+__device__ __forceinline__ void solve_instance(const SolveArgs& A, double* s, const int b, const int slot) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NREC = M::NREC;
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= A.B) return;
+    const int lane = threadIdx.x;
     const int N = A.N;
     const sddp_options& o = A.o;
     const double* x0 = A.x0 + size_t(b) * NX;
@@ -733,12 +741,12 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
     // candidate sets: set w of this instance = kSlots trajectories; the pass of an iteration writes set `wr`, the current
     // iterate lives in the other set (or in A.xs / A.us before the first accepted step)
     const size_t XS = size_t(N + 1) * NX, US = size_t(N) * NU;
-    double* xc = A.xc + size_t(b) * 2 * kSlots * XS;
-    double* uc = A.uc + size_t(b) * 2 * kSlots * US;
+    double* xc = A.xc + size_t(slot) * 2 * kSlots * XS;
+    double* uc = A.uc + size_t(slot) * 2 * kSlots * US;
     int wr = 0;
-    double* dft = A.dft + size_t(b) * N * NX;
-    double* gains = A.gains + size_t(b) * N * (NU * (NX + 1));
-    double* rec = A.rec + size_t(b) * (N + 1) * NREC;
+    double* dft = A.dft + size_t(slot) * N * NX;
+    double* gains = A.gains + size_t(slot) * N * (NU * (NX + 1));
+    double* rec = A.rec + size_t(slot) * (N + 1) * NREC;
 
     double J = 0.0, gap = 0.0;
     SDDP_T_DECL
@@ -855,20 +863,70 @@ __device__ __forceinline__ void solve_body(const SolveArgs& A, double* s) {
         st.cost = J; st.alpha = alpha; st.gap = gap; st.mu = mu; st.expected = expected;
         st.iters = iters; st.converged = converged; st.status = status; st.rollouts = rollouts;
         A.stats[b] = st;
+        A.hist[b] = iters;
     }
+    wave_sync();
 }
 
+// The launch as a work queue: one resident wavefront (slot) per workgroup, each solving instances until the queue is empty.
+// No workgroup ever waits for another one, so any grid size terminates; a slot's work buffers are private to its wavefront
+// (its own loads and stores are seen in program order), the per-instance inputs were written before the launch.
+// Every instance starts from freshly built LDS tables, so a result does not depend on which slot solved it or on what that
+// slot solved before: bit-identical to one launch per instance.
+template <class M>
+__device__ __forceinline__ void solve_queue(const SolveArgs& A, double* s) {
+    const int slot = blockIdx.x;
+    if (!A.qhead) {
+        if (slot < A.count) solve_instance<M>(A, s, A.first + slot, slot);
+        return;
+    }
+    while (true) {
+        int i = 0;
+        if (threadIdx.x == 0) i = atomicAdd(A.qhead, 1);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= A.count) break;                       // every wavefront reaches this: the head only grows
+        const int b = A.order ? A.order[i] : A.first + i;
+        solve_instance<M>(A, s, b, slot);
+    }
+}
 
 // two builds of the same body: the register allocation is the only difference (sddp_options.waves_per_simd)
 template <class M>
 __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double s[];
-    solve_body<M>(A, s);
+    solve_queue<M>(A, s);
 }
 template <class M>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2))) void solve_kernel_w2(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double s[];
-    solve_body<M>(A, s);
+    solve_queue<M>(A, s);
+}
+
+// Queue order for the next launch: instances [first, first + count) sorted by the iteration count of their previous solve,
+// longest first, never-solved ones before all others (longest-processing-time-first list scheduling: a launch ends with its
+// slowest instance, so the slow ones must start first; a fleet's robots recur tick after tick and the previous count is the
+// predictor at hand).  Counting sort in one workgroup; ties in arbitrary order (results do not depend on the order).
+constexpr int kOrderBins = 258;   // key = min(hist, 256), -1 -> 257
+__global__ __launch_bounds__(1024) void queue_order_kernel(int first, int count, const int* __restrict__ hist, int* __restrict__ order) {
+    __shared__ int bins[kOrderBins];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kOrderBins; i += 1024) bins[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < count; i += 1024) {
+        const int h = hist[first + i];
+        atomicAdd(&bins[h < 0 ? kOrderBins - 1 : (h > 256 ? 256 : h)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {   // exclusive prefix, largest key first
+        int run = 0;
+        for (int k = kOrderBins - 1; k >= 0; --k) { const int n = bins[k]; bins[k] = run; run += n; }
+    }
+    __syncthreads();
+    for (int i = tid; i < count; i += 1024) {
+        const int h = hist[first + i];
+        const int pos = atomicAdd(&bins[h < 0 ? kOrderBins - 1 : (h > 256 ? 256 : h)], 1);
+        order[pos] = first + i;
+    }
 }
 
 // -----------------------------------------------------------------------------------------------------------------

@@ -648,23 +648,21 @@ __device__ __forceinline__ void restore_tiles_mw(double* s, int tid) {
 
 // fused persistent solve, 4 waves per instance
 template <class M>
-__global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
-    extern __shared__ __attribute__((aligned(16))) double s[];
+__device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s, const int b, const int slot) {
     using L = LdsMW<M>;
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NREC = M::NREC;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    if (b >= A.B) return;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int N = A.N;
     const sddp_options& o = A.o;
     const double* x0 = A.x0 + size_t(b) * NX;
     const double* P = A.P + size_t(b) * (N + 1) * NP;
     double* xs = A.xs + size_t(b) * (N + 1) * NX;
     double* us = A.us + size_t(b) * N * NU;
-    double* xn = A.xn + size_t(b) * (N + 1) * NX;
-    double* un = A.un + size_t(b) * N * NU;
-    double* dft = A.dft + size_t(b) * N * NX;
-    double* gains = A.gains + size_t(b) * N * (NU * (NX + 1));
-    double* rec = A.rec + size_t(b) * (N + 1) * NREC;
+    double* xn = A.xn + size_t(slot) * (N + 1) * NX;      // work buffers: per slot (SolveArgs)
+    double* un = A.un + size_t(slot) * N * NU;
+    double* dft = A.dft + size_t(slot) * N * NX;
+    double* gains = A.gains + size_t(slot) * N * (NU * (NX + 1));
+    double* rec = A.rec + size_t(slot) * (N + 1) * NREC;
 
     double J = 0.0, gap = 0.0;
     SDDP_T_DECL
@@ -792,6 +790,29 @@ __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
         st.cost = J; st.alpha = alpha; st.gap = gap; st.mu = mu; st.expected = expected;
         st.iters = iters; st.converged = converged; st.status = status; st.rollouts = rollouts;
         A.stats[b] = st;
+        A.hist[b] = iters;
+    }
+    __syncthreads();
+}
+
+// work queue over the resident workgroups (see solve_queue in sddp_kernels.hpp); the queue position travels through LDS
+template <class M>
+__global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double s[];
+    __shared__ int q_pos;
+    const int slot = blockIdx.x;
+    if (!A.qhead) {
+        if (slot < A.count) solve_instance_mw<M>(A, s, A.first + slot, slot);
+        return;
+    }
+    while (true) {
+        if (threadIdx.x == 0) q_pos = atomicAdd(A.qhead, 1);
+        __syncthreads();
+        const int i = q_pos;
+        __syncthreads();
+        if (i >= A.count) break;
+        const int b = A.order ? A.order[i] : A.first + i;
+        solve_instance_mw<M>(A, s, b, slot);
     }
 }
 

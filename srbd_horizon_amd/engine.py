@@ -197,19 +197,33 @@ class DdpEngine:
         return x, u, sf, si
 
     def fetch(self):
-        """Copy the solution and stats of the last device solve to host numpy arrays."""
-        import torch
-        self.synchronize()
-        out = []
-        for which, shape, dt in ((0, (self.B, self.N + 1, self.nx), np.float64), (1, (self.B, self.N, self.nu), np.float64),
-                                 (2, (self.B,), _lib.STATS_DTYPE)):
-            p, n = self.device_buffer(which)
-            host = np.empty(shape, dtype=dt)
-            assert host.nbytes == n
-            _hip_memcpy_dtoh(host, p, n)
-            out.append(host)
-        self.stats = out[2]
-        return out[0], out[1], out[2]
+        """Copy the solution and stats of the last device solve to host numpy arrays (waits for the handle's stream)."""
+        x = np.empty((self.B, self.N + 1, self.nx))
+        u = np.empty((self.B, self.N, self.nu))
+        st = np.zeros(self.B, dtype=_lib.STATS_DTYPE)
+        self._chk(self.lib.sddp_fetch(self.h, _lib.ptr(x), _lib.ptr(u), _lib.ptr(st)))
+        self.stats = st
+        return x, u, st
+
+    # ---- the handle as a queue of instances (more instances than resident workgroups: one launch, work queue) -----------------
+    def _dev_or_null(self, t, shape):
+        return C.c_void_p(None) if t is None else self._dev(t, shape)
+
+    def load_range_device(self, first: int, count: int, x0=None, x=None, u=None):
+        """Initial state / warm start of the instances [first, first + count) from device tensors of `count` instances."""
+        self._chk(self.lib.sddp_load_range_device(self.h, int(first), int(count), self._dev_or_null(x0, (count, self.nx)),
+                                                  self._dev_or_null(x, (count, self.N + 1, self.nx)),
+                                                  self._dev_or_null(u, (count, self.N, self.nu))))
+
+    def solve_range_device(self, params, first: int, count: int):
+        """One asynchronous launch over the instances [first, first + count); `params` is the whole [B, N+1, np] tensor."""
+        self._chk(self.lib.sddp_solve_range_device(self.h, self._dev(params, (self.B, self.N + 1, self.np_)), int(first), int(count)))
+
+    def queue_info(self):
+        """(slots the work buffers exist for, grid of the last launch, queue length of the last launch or 0)."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.lib.sddp_queue_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
 
 def eval_knots(model: str, N: int, k, x, u, p, consts: dict | None = None):
@@ -227,17 +241,3 @@ def eval_knots(model: str, N: int, k, x, u, p, consts: dict | None = None):
     _lib.check(lib.sddp_eval_knots(_lib.MODEL_IDS[model], C.byref(cst), int(N), nk, _lib.ptr(k), _lib.ptr(x), _lib.ptr(u),
                                    _lib.ptr(p), _lib.ptr(f), _lib.ptr(F), _lib.ptr(H), _lib.ptr(g), _lib.ptr(L)))
     return f, F, H, g, L
-
-
-_hip = None
-
-
-def _hip_memcpy_dtoh(host: np.ndarray, dptr: int, nbytes: int):
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
-        _hip.hipMemcpy.restype = C.c_int
-        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    rc = _hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), nbytes, 2)  # hipMemcpyDeviceToHost
-    if rc != 0:
-        raise RuntimeError(f"hipMemcpy D2H failed: {rc}")

@@ -1,0 +1,130 @@
+"""The solve launch as a work queue: more instances than resident workgroups, one launch, every
+workgroup pulls instances until the queue is empty.  An instance's result must not depend on the slot that solved it, on what
+that slot solved before, on the queue order or on the range of the batch a launch covers: everything here is BIT-exact
+against one-workgroup-per-instance launches.  SDDP_MAX_SLOTS (diagnostic) shrinks the slot count so that a few hundred
+instances already queue; the last test runs BASELINE configs[3] (8 x 1024 instances, the 8 rank shards) through the real
+queue (2048 slots) against the C oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cport, ddp as oddp, models as omodels
+from srbd_horizon_amd import workload
+from srbd_horizon_amd.engine import DdpEngine
+from srbd_horizon_amd.fleet import FleetQueue
+
+pytestmark = pytest.mark.gpu
+
+OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsrbd_example.py:55-58
+
+
+def _engine(model, N, B, max_slots=None, **over):
+    old = os.environ.pop("SDDP_MAX_SLOTS", None)
+    if max_slots is not None:
+        os.environ["SDDP_MAX_SLOTS"] = str(max_slots)
+    try:
+        return DdpEngine(model, N, B, opts=dict(OPTS, **over))
+    finally:
+        os.environ.pop("SDDP_MAX_SLOTS", None)
+        if old is not None:
+            os.environ["SDDP_MAX_SLOTS"] = old
+
+
+def _solve(eng, batch):
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    return x.copy(), u.copy(), eng.stats.copy()
+
+
+@pytest.mark.parametrize("model,N,B,slots,wps", [("srbd13", 30, 300, 48, 1), ("srbd13", 30, 300, 37, 2), ("srbd37", 20, 7, 2, 1),
+                                                 ("lip30", 20, 9, 4, 1)])
+def test_queue_is_bit_identical_to_one_workgroup_per_instance(model, N, B, slots, wps):
+    batch = workload.make_batch(model, N, np.arange(B) + 11)
+    ref = _engine(model, N, B, waves_per_simd=wps)
+    assert ref.queue_info()[0] == B                                   # every instance has its own slot: no queue
+    x0, u0, s0 = _solve(ref, batch)
+    assert ref.queue_info()[1:] == (B, 0)
+    for order in (0, 1):
+        q = _engine(model, N, B, max_slots=slots, waves_per_simd=wps, queue_order=order)
+        assert q.queue_info()[0] == slots
+        for rep in range(2):                                          # second solve: the order comes from the first one's history
+            x, u, s = _solve(q, batch)
+            assert q.queue_info()[1:] == (slots, B)
+            np.testing.assert_array_equal(x, x0)
+            np.testing.assert_array_equal(u, u0)
+            for f in s0.dtype.names:
+                np.testing.assert_array_equal(s[f], s0[f], err_msg=f)
+    if model != "lip30":                                              # (the LQ problem takes one iteration everywhere)
+        assert s0["iters"].max() > s0["iters"].min()                  # the instances do differ in length
+
+
+def test_ranges_of_a_handle_solve_like_separate_batches():
+    """The fleet queue of bench.py: blocks of a large handle loaded and solved range by range."""
+    N, B, D = 30, 64, 3
+    dev = torch.device("cuda", 0)
+    batch = workload.make_batch("srbd13", N, np.arange(B) + 500)
+    ref = _engine("srbd13", N, B)
+    x0, u0, s0 = _solve(ref, batch)
+    eng = _engine("srbd13", N, D * B, max_slots=40, waves_per_simd=2)
+    eng.use_torch_stream(torch.cuda.current_stream())
+    t = {k: torch.from_numpy(batch[k]).to(dev) for k in ("x0", "xs", "us", "params")}
+    P_all = t["params"].repeat(D, 1, 1).contiguous()
+    fleet = FleetQueue(eng, P_all, B, D)
+    for steps in (1, 3, 5):                                           # partial handle, full handle, wrap-around (two launches)
+        before = fleet.launches
+        for _ in range(steps):
+            fleet.submit(t["x0"], t["xs"], t["us"])
+        fleet.flush()
+        assert fleet.launches - before == -(-steps // D)
+        x, u, s = eng.fetch()
+        last = steps - D * ((steps - 1) // D)                         # blocks solved by the last launch
+        for blk in range(last):
+            sl = slice(blk * B, (blk + 1) * B)
+            np.testing.assert_array_equal(x[sl], x0)
+            np.testing.assert_array_equal(u[sl], u0)
+            np.testing.assert_array_equal(s["iters"][sl], s0["iters"])
+            np.testing.assert_array_equal(s["cost"][sl], s0["cost"])
+    with pytest.raises(RuntimeError):
+        eng.solve_range_device(P_all, D * B - 1, 2)                   # range past the batch
+    with pytest.raises(RuntimeError):
+        eng.backward(np.zeros((D * B, N + 1, 19)))                    # phase-level entry points need one slot per instance
+
+
+def test_non_finite_options_are_rejected():
+    for k, v in (("alpha_0", float("inf")), ("mu_max", float("nan")), ("beta", float("nan")), ("gap_tol", float("inf")),
+                 ("mu_max", 1e-7), ("queue_order", 2)):
+        with pytest.raises(RuntimeError):
+            DdpEngine("srbd13", 30, 1, opts=dict(OPTS, **{k: v}))
+
+
+def test_configs3_all_eight_rank_shards_match_the_c_oracle():
+    """BASELINE configs[3]: 8192 instances = the shards rank r = 0..7 of bench.py solve (seeds r * 1024 + arange(1024)), here
+    through ONE handle on one GPU: a queue of 8192 instances on the device's resident slots, against the plain-C oracle."""
+    N, B, R = 30, 1024, 8
+    seeds = np.arange(R * B)
+    batch = workload.make_batch("srbd13", N, seeds)
+    eng = DdpEngine("srbd13", N, R * B, opts=dict(OPTS, waves_per_simd=2))
+    x, u, st = _solve(eng, batch)
+    slots, grid, queued = eng.queue_info()
+    assert queued == R * B and grid == slots < R * B
+    xo, uo, so = cport.solve_batch(omodels.RobotConsts(**batch["consts"]), oddp.DdpOptions(**OPTS), batch["x0"], batch["params"],
+                                   batch["xs"], batch["us"], threads=min(16, os.cpu_count() or 1))
+    it_o = so[:, 1].astype(int)
+    same = st["iters"] == it_o
+    per_shard = [int((~same[r * B:(r + 1) * B]).sum()) for r in range(R)]
+    print(f"configs[3]: {int((~same).sum())} of {R * B} instances with a different iteration count, per rank shard {per_shard}; "
+          f"slots {slots}; iterations mean {st['iters'].mean():.2f} max {st['iters'].max()}")
+    # chaotic early iterations of a few hard instances may pick another step length on a last-bit difference: allow 1 % per shard
+    assert max(per_shard) <= B // 100, per_shard
+    ex = np.max(np.abs(x[same] - xo[same]), axis=(1, 2))
+    eu = np.max(np.abs(u[same] - uo[same]), axis=(1, 2))
+    assert ex.max() <= 1e-4 and eu.max() <= 1e-4, (ex.max(), eu.max())          # north_star tolerance
+    np.testing.assert_allclose(st["cost"][same], so[same, 0], rtol=1e-8)
+    np.testing.assert_array_equal(st["converged"][same], so[same, 2].astype(int))
+    # the instances that took another path must still end at an optimum of the same quality
+    d = ~same
+    assert np.all(np.isfinite(x[d])) and np.all(np.isfinite(u[d]))
+    np.testing.assert_array_equal(st["converged"][d], so[d, 2].astype(int))
+    np.testing.assert_allclose(st["cost"][d], so[d, 0], rtol=1e-5)
