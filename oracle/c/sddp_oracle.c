@@ -386,7 +386,7 @@ int oracle_srbd13_solve(const double* cpack, int N, const double* x0, const doub
         }
         if (!accepted) {
             if (theta != 0.0) { theta = 0.0; continue; }
-            converged = 1; status = 0; alpha = 0.0; break;
+            status = 4; converged = (gap <= gap_tol && expected <= ths * fmax(1.0, fabs(J))) ? 1 : 0; alpha = 0.0; break;
         }
         alpha = a;
         theta = (second_order && a == a0) ? 1.0 : 0.0;

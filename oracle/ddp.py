@@ -15,7 +15,8 @@ steps; tests compare the two iteration by iteration.
     forward   xh_0 = x0 ; uh_k = u_k + a k_k + K_k (xh_k - x_k) ; xh_{k+1} = f(xh_k,uh_k) - (1-a) d_{k+1}
     accept    phi = J + rho*||d||_1 ;  phi(a) - phi(0) <= beta * (a (dV1+G1) + a^2 (dV2+G2) - a rho ||d||_1) + slack
     stop      expected reduction -(dV1+dV2) < cost_reduction_ths (and gaps closed)  -> converged
-              a < alpha_converge_threshold                                         -> converged (no progress)
+              a < alpha_converge_threshold  -> stop, status 4; converged only with closed gaps and
+                                               expected <= cost_reduction_ths * max(1, |J|)
               |J_old - J_new| < cost_reduction_ths (and gaps closed)               -> converged
 """
 from __future__ import annotations
@@ -51,7 +52,7 @@ class DdpResult:
     alpha: float
     gap: float
     mu: float
-    status: int          # 0 ok, 1 max_iters, 2 regularisation overflow, 3 non-finite
+    status: int          # 0 ok, 1 max_iters, 2 regularisation overflow, 3 non-finite, 4 line search exhausted
     trace: list
 
 
@@ -188,7 +189,11 @@ def solve(model, x0, P, xs_ws, us_ws, opt: DdpOptions | None = None) -> DdpResul
             if theta:
                 theta = 0.0                       # redo this iteration with the plain Gauss-Newton step
                 continue
-            converged, status = True, 0          # alpha fell below alpha_converge_threshold (App. C)
+            # alpha fell below alpha_converge_threshold (App. C: "stop").  No step length decreases the merit function any
+            # more; that is an optimum only if the multiple-shooting gaps are closed and the model predicts (next to) no
+            # decrease either: expected <= cost_reduction_ths relative to the cost.  Otherwise: stalled, status 4.
+            status = 4
+            converged = bool(gap <= opt.gap_tol and expected <= opt.cost_reduction_ths * max(1.0, abs(J)))
             alpha = 0.0
             break
         alpha = a

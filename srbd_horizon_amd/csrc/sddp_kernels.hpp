@@ -824,7 +824,10 @@ __device__ __forceinline__ void solve_instance(const SolveArgs& A, double* s, co
                 }
                 if (accepted) break;
                 if (theta != 0.0) { theta = 0.0; continue; }                       // redo with the plain Gauss-Newton step
-                alpha = 0.0; converged = 1; status = 0; stop = true;               // alpha fell below alpha_converge_threshold
+                // alpha fell below alpha_converge_threshold: stop.  An optimum only with closed gaps and (next to) no predicted
+                // decrease either; otherwise the line search has stalled (status 4, not converged)
+                alpha = 0.0; status = 4; stop = true;
+                converged = (gap <= o.gap_tol && expected <= o.cost_reduction_ths * fmax(1.0, fabs(J))) ? 1 : 0;
                 break;
             } while (true);
             if (stop) break;

@@ -758,7 +758,11 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
                 break;
             } while (true);
             if (stop) break;
-            if (!accepted) { alpha = 0.0; converged = 1; status = 0; break; }   // alpha below the threshold: no progress possible
+            if (!accepted) {   // alpha below the threshold: stop; converged only with closed gaps and no predicted decrease (status 4)
+                alpha = 0.0; status = 4;
+                converged = (gap <= o.gap_tol && expected <= o.cost_reduction_ths * fmax(1.0, fabs(J))) ? 1 : 0;
+                break;
+            }
             alpha = a_win;
             const double dJ = J - J_win;
             J = J_win;

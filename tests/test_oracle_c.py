@@ -42,3 +42,25 @@ def test_c_solve_matches_numpy_solve(barrier):
         assert int(st[b, 1]) == r.iters and bool(st[b, 2]) == r.converged and st[b, 3] == r.alpha
         assert np.max(np.abs(xs[b] - r.xs)) <= 1e-8 and np.max(np.abs(us[b] - r.us)) <= 1e-8
         assert abs(st[b, 0] - r.cost) <= 1e-10 * abs(r.cost)
+
+
+def test_exhausted_line_search_is_a_stall_not_convergence_in_both_oracles():
+    """alpha below alpha_converge_threshold stops the solve; with open multiple-shooting gaps that is status 4
+    and NOT converged.  With closed gaps and no predicted decrease left it still counts as converged."""
+    N = 30
+    batch = workload.make_batch("srbd13", N, [7])
+    cst = omodels.RobotConsts()
+    m = omodels.make_model("srbd13", cst)
+    opts = oddp.DdpOptions(max_iters=5, alpha_converge_threshold=0.5, beta=1e-3)       # seed 7 needs alpha = 0.125 in iteration 1
+    r = oddp.solve(m, batch["x0"][0], batch["params"][0], batch["xs"][0], batch["us"][0], opts)
+    _, _, st = cport.solve_batch(cst, opts, batch["x0"], batch["params"], batch["xs"], batch["us"])
+    assert r.status == 4 and not r.converged and r.iters == 0 and r.gap > opts.gap_tol
+    assert int(st[0, 6]) == 4 and int(st[0, 2]) == 0 and int(st[0, 1]) == 0
+    # restart from the optimum with an impossible Armijo fraction: nothing is accepted, but the point is optimal
+    full = oddp.DdpOptions(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
+    opt = oddp.solve(m, batch["x0"][0], batch["params"][0], batch["xs"][0], batch["us"][0], full)
+    assert opt.converged and opt.status == 0
+    hard = oddp.DdpOptions(max_iters=5, alpha_converge_threshold=0.5, beta=1e6, cost_reduction_ths=1e-12)
+    r2 = oddp.solve(m, batch["x0"][0], batch["params"][0], opt.xs, opt.us, hard)
+    _, _, st2 = cport.solve_batch(cst, hard, batch["x0"], batch["params"], opt.xs[None], opt.us[None])
+    assert r2.status in (0, 4) and r2.converged and int(st2[0, 2]) == 1 and int(st2[0, 6]) == r2.status
