@@ -1,31 +1,29 @@
-/* TEST INFRASTRUCTURE ONLY -- plain C restatement of the srbd13 problem and of the MS-DDP iteration (same steps, same
- * order as oracle/models.py + oracle/ddp.py, which carry the reference file:line citations).
+/* TEST INFRASTRUCTURE ONLY -- plain C restatement of the three problems (srbd13, srbd37, lip30) and, through ddp_engine.inc, of
+ * the MS-DDP iteration (same steps, same order as oracle/models.py + oracle/ddp.py, which carry the reference file:line
+ * citations).
  * PARITY UNPINNED upstream (the reference engine `pyddp` is absent): this file is pinned against the numpy oracle in
- * tests/test_oracle_c.py.  Used for (1) the `cpu_baseline` leg of bench.py (kind "port"), (2) large-batch parity checks.
- * Never linked into or called from the product (srbd_horizon_amd/).
+ * tests/test_oracle_c.py.  Used for (1) the `cpu_baseline` leg of bench.py (kind "port"), (2) large-batch / long-horizon parity
+ * checks.  Never linked into or called from the product (srbd_horizon_amd/).
  *
  * Reference lines restated: dynamics prb.py:92-110 (fSRBD, element-wise inertia prb.py:99, Euler ddp.py:228-230);
- * costs prb.py:184-204 through ddp.py:179-226; solver options ddp.py:14-35.
+ * costs and penalties prb.py:166-204 through ddp.py:179-226; LIP prb.py:315-328, :379-402; solver options ddp.py:14-35.
  */
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
-#define NX 13
-#define NU 6
-#define NZ 19
-#define NP 19
-#define NR 39 /* residual rows of a stage node: 11 state + 18 input (+ 10 friction-cone barrier rows when enabled) */
 #define GRAV 9.81
+#define CW 1e6 /* equality-constraint weight, ddp.py:181 */
 
 typedef struct {
     double dt, inv_ms, Is[9], com_z, w_rz, w_rd, w_w, w_f, w_sw, gq, lever;
     double mu_lin, bar_w, bar_s;   /* friction-cone exponential barrier (oracle/models.py _force_rows): off when bar_w == 0 */
+    double w_rel, w_zmp, lip_h, feet[12];
     int inertia_mode;
 } consts_t;
 
 /* packed constants from Python: m, I[9], com_z, dt, force_scaling, r_gain, rdot_gain, w_gain, fsw, qddot, minf, inertia_mode, lever,
- * friction_cone_coefficient, friction_barrier_weight, friction_barrier_sharpness */
+ * friction_cone_coefficient, friction_barrier_weight, friction_barrier_sharpness, rel_pos_gain, zmp_gain, lip_height, feet[12] */
 static void unpack_consts(const double* c, consts_t* k) {
     const double m = c[0], fs = c[12];
     k->inv_ms = fs / m;
@@ -35,6 +33,8 @@ static void unpack_consts(const double* c, consts_t* k) {
     k->w_sw = fs * fs * c[16]; k->gq = c[17]; k->w_f = fs * fs * c[18];
     k->inertia_mode = (int)c[19]; k->lever = c[20];
     k->mu_lin = c[21] / sqrt(2.0); k->bar_w = c[22]; k->bar_s = c[23];
+    k->w_rel = c[24]; k->w_zmp = c[25]; k->lip_h = c[26];
+    for (int i = 0; i < 12; ++i) k->feet[i] = c[27 + i];
 }
 
 static void cross(const double* a, const double* b, double* o) {
@@ -87,175 +87,6 @@ static void world_inertia_d(const consts_t* c, const double* R, const double* dR
         mm3(c->Is, Rt, T); mm3(dR, T, U); for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dM[3 * i + j] = U[3 * i + j] + U[3 * j + i]; }
 }
 
-typedef struct { double R[9], M[9], Mi[9], wdot[3], rddot[3]; } core_t;
-
-/* p = rdot_ref(3) | w_ref(3) | otg | oref(4) | cL(3) | cR(3) | swL | swR */
-static void core(const consts_t* c, const double* x, const double* u, const double* p, core_t* k) {
-    const double *r = x, *o = x + 3, *w = x + 10;
-    quat_to_rot(o, k->R); world_inertia(c, k->R, k->M); inv3(k->M, k->Mi);
-    double tau[3] = {0, 0, 0}, fs[3] = {0, 0, 0}, Mw[3], g[3];
-    for (int i = 0; i < 2; ++i) {
-        const double* cp = p + 11 + 3 * i; const double* f = u + 3 * i;
-        double l[3] = {cp[0] - r[0], cp[1] - r[1], cp[2] - r[2]}, t[3];
-        cross(l, f, t);
-        for (int a = 0; a < 3; ++a) { tau[a] += c->lever * t[a]; fs[a] += f[a]; }
-    }
-    mv3(k->M, w, Mw); cross(w, Mw, g);
-    for (int a = 0; a < 3; ++a) tau[a] -= g[a];
-    mv3(k->Mi, tau, k->wdot);
-    k->rddot[0] = fs[0] * c->inv_ms; k->rddot[1] = fs[1] * c->inv_ms; k->rddot[2] = fs[2] * c->inv_ms - GRAV;
-}
-
-static void dyn(const consts_t* c, const double* x, const double* u, const double* p, double* xn) {
-    core_t k; core(c, x, u, p, &k);
-    const double *o = x + 3, *w = x + 10, dt = c->dt;
-    double wxo[3]; cross(w, o, wxo);
-    for (int a = 0; a < 3; ++a) {
-        xn[a] = x[a] + dt * x[7 + a];
-        xn[3 + a] = o[a] + dt * 0.5 * (o[3] * w[a] + wxo[a]);
-        xn[7 + a] = x[7 + a] + dt * k.rddot[a];
-        xn[10 + a] = x[10 + a] + dt * k.wdot[a];
-    }
-    xn[6] = o[3] - dt * 0.5 * (w[0] * o[0] + w[1] * o[1] + w[2] * o[2]);
-}
-
-/* A = d wdot / d [r(3) o(4) w(3) fL(3) fR(3)] (3 x 16) */
-static void wdot_jac(const consts_t* c, const double* x, const double* u, const double* p, const core_t* k, double* A) {
-    const double *r = x, *o = x + 3, *w = x + 10;
-    double S[9], T[9], sf[3] = {0, 0, 0};
-    for (int i = 0; i < 2; ++i) for (int a = 0; a < 3; ++a) sf[a] += c->lever * u[3 * i + a];
-    skew(sf, S); mm3(k->Mi, S, T);
-    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[a * 16 + b] = T[3 * a + b];
-    double Mw[3], SMw[9], Sw[9], SwM[9], U[9];
-    mv3(k->M, w, Mw); skew(Mw, SMw); skew(w, Sw); mm3(Sw, k->M, SwM);
-    for (int i = 0; i < 9; ++i) U[i] = SMw[i] - SwM[i];
-    mm3(k->Mi, U, T);
-    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[a * 16 + 7 + b] = T[3 * a + b];
-    for (int q = 0; q < 4; ++q) {
-        double dR[9], dM[9], a1[3], b1[3], cr[3], t[3], col[3];
-        quat_to_rot_d(o, q, dR); world_inertia_d(c, k->R, dR, dM);
-        mv3(dM, k->wdot, a1); mv3(dM, w, b1); cross(w, b1, cr);
-        for (int a = 0; a < 3; ++a) t[a] = -(a1[a] + cr[a]);
-        mv3(k->Mi, t, col);
-        for (int a = 0; a < 3; ++a) A[a * 16 + 3 + q] = col[a];
-    }
-    for (int i = 0; i < 2; ++i) {
-        const double* cp = p + 11 + 3 * i;
-        double l[3] = {c->lever * (cp[0] - r[0]), c->lever * (cp[1] - r[1]), c->lever * (cp[2] - r[2])};
-        skew(l, S); mm3(k->Mi, S, T);
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[a * 16 + 10 + 3 * i + b] = T[3 * a + b];
-    }
-}
-static const int ZCOL[16] = {0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18};
-
-static void dyn_jac(const consts_t* c, const double* x, const double* u, const double* p, double* F /*13x19*/) {
-    core_t k; core(c, x, u, p, &k);
-    double A[48]; wdot_jac(c, x, u, p, &k, A);
-    const double *o = x + 3, *w = x + 10, dt = c->dt;
-    memset(F, 0, sizeof(double) * NX * NZ);
-    for (int i = 0; i < NX; ++i) F[i * NZ + i] = 1.0;
-    for (int a = 0; a < 3; ++a) {
-        F[a * NZ + 7 + a] += dt;
-        for (int i = 0; i < 2; ++i) F[(7 + a) * NZ + NX + 3 * i + a] = dt * c->inv_ms;
-        for (int j = 0; j < 16; ++j) F[(10 + a) * NZ + ZCOL[j]] += dt * A[a * 16 + j];
-    }
-    const double Jo[16] = {0, -0.5 * w[2], 0.5 * w[1], 0.5 * w[0], 0.5 * w[2], 0, -0.5 * w[0], 0.5 * w[1],
-                           -0.5 * w[1], 0.5 * w[0], 0, 0.5 * w[2], -0.5 * w[0], -0.5 * w[1], -0.5 * w[2], 0};
-    const double Jw[12] = {0.5 * o[3], 0.5 * o[2], -0.5 * o[1], -0.5 * o[2], 0.5 * o[3], 0.5 * o[0],
-                           0.5 * o[1], -0.5 * o[0], 0.5 * o[3], -0.5 * o[0], -0.5 * o[1], -0.5 * o[2]};
-    for (int a = 0; a < 4; ++a) {
-        for (int b = 0; b < 4; ++b) F[(3 + a) * NZ + 3 + b] += dt * Jo[4 * a + b];
-        for (int b = 0; b < 3; ++b) F[(3 + a) * NZ + 10 + b] += dt * Jw[3 * a + b];
-    }
-}
-
-/* stacked residual and Jacobian of node k; terminal: u == NULL.  Returns the number of rows. */
-static int residual(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J /*NR x NZ or NULL*/) {
-    int n = 0;
-    if (J) memset(J, 0, sizeof(double) * NR * NZ);
-    if (!u || k >= 1) {
-        const double g = sqrt(c->w_rz);
-        r[n] = g * (x[2] - c->com_z); if (J) J[n * NZ + 2] = g; ++n;
-        const double *o = x + 3, *q = p + 7, otg = p[6];
-        double oxq[3]; cross(o, q, oxq);
-        for (int a = 0; a < 3; ++a) r[n + a] = otg * (o[3] * q[a] + q[3] * o[a] + oxq[a]);
-        r[n + 3] = otg * (o[3] * q[3] - (o[0] * q[0] + o[1] * q[1] + o[2] * q[2]) - 1.0);
-        if (J) {
-            double Sq[9]; skew(q, Sq);
-            for (int a = 0; a < 3; ++a) {
-                for (int b = 0; b < 3; ++b) J[(n + a) * NZ + 3 + b] = otg * ((a == b ? q[3] : 0.0) - Sq[3 * a + b]);
-                J[(n + a) * NZ + 6] = otg * q[a];
-                J[(n + 3) * NZ + 3 + a] = -otg * q[a];
-            }
-            J[(n + 3) * NZ + 6] = otg * q[3];
-        }
-        n += 4;
-        const double gd = sqrt(c->w_rd), gw = sqrt(c->w_w);
-        for (int a = 0; a < 3; ++a) { r[n + a] = gd * (x[7 + a] - p[a]); if (J) J[(n + a) * NZ + 7 + a] = gd; }
-        n += 3;
-        for (int a = 0; a < 3; ++a) { r[n + a] = gw * (x[10 + a] - p[3 + a]); if (J) J[(n + a) * NZ + 10 + a] = gw; }
-        n += 3;
-    }
-    if (u) {
-        core_t kk; core(c, x, u, p, &kk);
-        const double g = sqrt(c->gq);
-        for (int a = 0; a < 3; ++a) { r[n + a] = g * kk.rddot[a]; r[n + 3 + a] = g * kk.wdot[a]; }
-        if (J) {
-            double A[48]; wdot_jac(c, x, u, p, &kk, A);
-            for (int a = 0; a < 3; ++a) {
-                for (int i = 0; i < 2; ++i) J[(n + a) * NZ + NX + 3 * i + a] = g * c->inv_ms;
-                for (int j = 0; j < 16; ++j) J[(n + 3 + a) * NZ + ZCOL[j]] = g * A[a * 16 + j];
-            }
-        }
-        n += 6;
-        for (int i = 0; i < 2; ++i) {
-            const double s1 = 1.0 - p[17 + i];
-            const double g1 = sqrt(c->w_f), g2 = sqrt(c->w_sw) * s1;
-            for (int a = 0; a < 3; ++a) { r[n + a] = g1 * u[3 * i + a]; if (J) J[(n + a) * NZ + NX + 3 * i + a] = g1; }
-            n += 3;
-            for (int a = 0; a < 3; ++a) { r[n + a] = g2 * u[3 * i + a]; if (J) J[(n + a) * NZ + NX + 3 * i + a] = g2; }
-            n += 3;
-            if (c->bar_w > 0.0) {   /* r_j = sqrt(w) exp(s a_j.f / 2), rows of the linearised cone A f <= 0 */
-                const double ml = c->mu_lin;
-                const double A[5][3] = {{1, 0, -ml}, {-1, 0, -ml}, {0, 1, -ml}, {0, -1, -ml}, {0, 0, -1}};
-                for (int j = 0; j < 5; ++j) {
-                    const double gj = A[j][0] * u[3 * i] + A[j][1] * u[3 * i + 1] + A[j][2] * u[3 * i + 2];
-                    const double rj = sqrt(c->bar_w) * exp(0.5 * c->bar_s * gj);
-                    r[n + j] = rj;
-                    if (J) for (int a = 0; a < 3; ++a) J[(n + j) * NZ + NX + 3 * i + a] = 0.5 * c->bar_s * rj * A[j][a];
-                }
-                n += 5;
-            }
-        }
-    }
-    return n;
-}
-
-static double cost(const consts_t* c, const double* x, const double* u, const double* p, int k) {
-    double r[NR]; const int n = residual(c, x, u, p, k, r, NULL);
-    double s = 0; for (int i = 0; i < n; ++i) s += r[i] * r[i]; return s;
-}
-/* g = 2 J^T r (NZ), H = 2 J^T J (NZ x NZ) */
-static double cost_derivs(const consts_t* c, const double* x, const double* u, const double* p, int k, double* g, double* H) {
-    double r[NR], J[NR * NZ]; const int n = residual(c, x, u, p, k, r, J);
-    double s = 0;
-    memset(g, 0, sizeof(double) * NZ); memset(H, 0, sizeof(double) * NZ * NZ);
-    for (int i = 0; i < n; ++i) {
-        s += r[i] * r[i];
-        for (int a = 0; a < NZ; ++a) {
-            const double ja = J[i * NZ + a]; if (ja == 0.0) continue;
-            g[a] += 2 * ja * r[i];
-            for (int b = 0; b < NZ; ++b) H[a * NZ + b] += 2 * ja * J[i * NZ + b];
-        }
-    }
-    return s;
-}
-
-static double total_cost(const consts_t* c, int N, const double* xs, const double* us, const double* P) {
-    double J = 0; for (int k = 0; k < N; ++k) J += cost(c, xs + k * NX, us + k * NU, P + k * NP, k);
-    return J + cost(c, xs + N * NX, NULL, P + N * NP, N);
-}
-
 /* Cholesky of an n x n SPD matrix (lower, in place); returns 0 on failure */
 static int chol(double* A, int n) {
     for (int j = 0; j < n; ++j) {
@@ -267,160 +98,426 @@ static int chol(double* A, int n) {
     return 1;
 }
 
-static int backward(const consts_t* c, int N, const double* xs, const double* us, const double* P, const double* d, double mu,
-                    double theta, double* K /*N x NU x NX*/, double* kff /*N x NU*/, double* sc /*dV1,dV2,G1,G2*/) {
-    double Vx[NX], Vxx[NX * NX], g[NZ], H[NZ * NZ];
-    cost_derivs(c, xs + N * NX, NULL, P + N * NP, N, g, H);
-    for (int i = 0; i < NX; ++i) { Vx[i] = g[i]; for (int j = 0; j < NX; ++j) Vxx[i * NX + j] = H[i * NZ + j]; }
-    double dV1 = 0, dV2 = 0, G1 = 0, G2 = 0;
-    for (int k = N - 1; k >= 0; --k) {
-        double F[NX * NZ], vp[NX], W[NX * NZ], Q[NZ * NZ], q[NZ];
-        dyn_jac(c, xs + k * NX, us + k * NU, P + k * NP, F);
-        cost_derivs(c, xs + k * NX, us + k * NU, P + k * NP, k, g, H);
-        const double* dk = d + k * NX;
-        for (int i = 0; i < NX; ++i) {
-            double s = 0; for (int j = 0; j < NX; ++j) s += Vxx[i * NX + j] * dk[j];
-            vp[i] = Vx[i] + s; G1 += dk[i] * Vx[i]; G2 += 0.5 * dk[i] * s;
-        }
-        for (int i = 0; i < NX; ++i) for (int j = 0; j < NZ; ++j) { double s = 0; for (int l = 0; l < NX; ++l) s += Vxx[i * NX + l] * F[l * NZ + j]; W[i * NZ + j] = s; }
-        for (int a = 0; a < NZ; ++a) {
-            double s = g[a]; for (int l = 0; l < NX; ++l) s += F[l * NZ + a] * vp[l]; q[a] = s;
-            for (int b = 0; b < NZ; ++b) { double t = H[a * NZ + b]; for (int l = 0; l < NX; ++l) t += F[l * NZ + a] * W[l * NZ + b]; Q[a * NZ + b] = t; }
-        }
-        if (theta != 0.0) { /* exact bilinear-torque term: Qux[f_a][r_b] -= theta * s * skew(y)[a][b], y = I_w^-1 (dt v'_w) */
-            double R[9], M[9], Mi[9], lam[3], y[3], S[9];
-            quat_to_rot(xs + k * NX + 3, R); world_inertia(c, R, M); inv3(M, Mi);
-            for (int a = 0; a < 3; ++a) lam[a] = c->dt * vp[10 + a];
-            mv3(Mi, lam, y); skew(y, S);
-            for (int i = 0; i < 2; ++i) for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) {
-                const double v = -theta * c->lever * S[3 * a + b2];
-                Q[(NX + 3 * i + a) * NZ + b2] += v; Q[b2 * NZ + NX + 3 * i + a] += v;
-            }
-        }
-        double L[NU * NU], Quu[NU * NU];
-        for (int i = 0; i < NU; ++i) for (int j = 0; j < NU; ++j) Quu[i * NU + j] = L[i * NU + j] = Q[(NX + i) * NZ + NX + j] + (i == j ? mu : 0.0);
-        if (!chol(L, NU)) return 0;
-        /* solve for the NX+1 right-hand sides [Qu | Qux] */
-        double sol[NU * (NX + 1)];
-        for (int col = 0; col <= NX; ++col) {
-            double y[NU];
-            for (int i = 0; i < NU; ++i) { double s = col == 0 ? q[NX + i] : Q[(NX + i) * NZ + (col - 1)]; for (int kx = 0; kx < i; ++kx) s -= L[i * NU + kx] * y[kx]; y[i] = s / L[i * NU + i]; }
-            for (int i = NU - 1; i >= 0; --i) { double s = y[i]; for (int kx = i + 1; kx < NU; ++kx) s -= L[kx * NU + i] * y[kx]; y[i] = s / L[i * NU + i]; }
-            for (int i = 0; i < NU; ++i) sol[i * (NX + 1) + col] = -y[i];
-        }
-        double* Kk = K + (size_t)k * NU * NX; double* kk = kff + k * NU;
-        for (int i = 0; i < NU; ++i) { kk[i] = sol[i * (NX + 1)]; for (int j = 0; j < NX; ++j) Kk[i * NX + j] = sol[i * (NX + 1) + 1 + j]; }
-        for (int i = 0; i < NU; ++i) { dV1 += kk[i] * q[NX + i]; double s = 0; for (int j = 0; j < NU; ++j) s += Quu[i * NU + j] * kk[j]; dV2 += 0.5 * kk[i] * s; }
-        double Vn[NX * NX];
-        for (int a = 0; a < NX; ++a) {
-            double s = q[a]; for (int i = 0; i < NU; ++i) s += Q[(NX + i) * NZ + a] * kk[i]; Vx[a] = s;
-            for (int b = 0; b < NX; ++b) { double t = Q[a * NZ + b]; for (int i = 0; i < NU; ++i) t += Q[(NX + i) * NZ + a] * Kk[i * NX + b]; Vn[a * NX + b] = t; }
-        }
-        for (int a = 0; a < NX; ++a) for (int b = 0; b < NX; ++b) Vxx[a * NX + b] = 0.5 * (Vn[a * NX + b] + Vn[b * NX + a]);
+/* ---- SRBD accelerations for nc contacts (Horizon kin_dyn.fSRBD, prb.py:99; oracle/models.py srbd_acc / srbd_acc_jac) ---- */
+typedef struct { double R[9], M[9], Mi[9], wdot[3], rddot[3]; } core_t;
+typedef struct { double Wr[9], Wo[12], Ww[9], Wc[4][9], Wf[4][9]; } corejac_t;   /* d wdot / d r, o, w, c_i, f_i */
+
+static void core_n(const consts_t* c, const double* r, const double* o, const double* w, int nc, const double* const* cs,
+                   const double* const* fs, core_t* k) {
+    quat_to_rot(o, k->R); world_inertia(c, k->R, k->M); inv3(k->M, k->Mi);
+    double tau[3] = {0, 0, 0}, fsum[3] = {0, 0, 0}, Mw[3], g[3];
+    for (int i = 0; i < nc; ++i) {
+        const double* cp = cs[i]; const double* f = fs[i];
+        double l[3] = {cp[0] - r[0], cp[1] - r[1], cp[2] - r[2]}, t[3];
+        cross(l, f, t);
+        for (int a = 0; a < 3; ++a) { tau[a] += c->lever * t[a]; fsum[a] += f[a]; }
     }
-    sc[0] = dV1; sc[1] = dV2; sc[2] = G1; sc[3] = G2;
-    return 1;
+    mv3(k->M, w, Mw); cross(w, Mw, g);
+    for (int a = 0; a < 3; ++a) tau[a] -= g[a];
+    mv3(k->Mi, tau, k->wdot);
+    k->rddot[0] = fsum[0] * c->inv_ms; k->rddot[1] = fsum[1] * c->inv_ms; k->rddot[2] = fsum[2] * c->inv_ms - GRAV;
+}
+static void corejac_n(const consts_t* c, const double* r, const double* o, const double* w, int nc, const double* const* cs,
+                      const double* const* fs, const core_t* k, corejac_t* J) {
+    double S[9], sf[3] = {0, 0, 0};
+    for (int i = 0; i < nc; ++i) for (int a = 0; a < 3; ++a) sf[a] += c->lever * fs[i][a];
+    skew(sf, S); mm3(k->Mi, S, J->Wr);
+    double Mw[3], SMw[9], Sw[9], SwM[9], U[9];
+    mv3(k->M, w, Mw); skew(Mw, SMw); skew(w, Sw); mm3(Sw, k->M, SwM);
+    for (int i = 0; i < 9; ++i) U[i] = SMw[i] - SwM[i];
+    mm3(k->Mi, U, J->Ww);
+    for (int q = 0; q < 4; ++q) {
+        double dR[9], dM[9], a1[3], b1[3], cr[3], t[3], col[3];
+        quat_to_rot_d(o, q, dR); world_inertia_d(c, k->R, dR, dM);
+        mv3(dM, k->wdot, a1); mv3(dM, w, b1); cross(w, b1, cr);
+        for (int a = 0; a < 3; ++a) t[a] = -(a1[a] + cr[a]);
+        mv3(k->Mi, t, col);
+        for (int a = 0; a < 3; ++a) J->Wo[a * 4 + q] = col[a];
+    }
+    for (int i = 0; i < nc; ++i) {
+        double l[3] = {c->lever * (cs[i][0] - r[0]), c->lever * (cs[i][1] - r[1]), c->lever * (cs[i][2] - r[2])};
+        skew(l, S); mm3(k->Mi, S, J->Wf[i]);
+        double nf[3] = {-c->lever * fs[i][0], -c->lever * fs[i][1], -c->lever * fs[i][2]};
+        skew(nf, S); mm3(k->Mi, S, J->Wc[i]);
+    }
+}
+/* quaternion kinematics odot = 1/2 [w;0] (x) o and its Jacobians (prb.py:107-108) */
+static void quat_step(const double* o, const double* w, double dt, double* on) {
+    double wxo[3]; cross(w, o, wxo);
+    for (int a = 0; a < 3; ++a) on[a] = o[a] + dt * 0.5 * (o[3] * w[a] + wxo[a]);
+    on[3] = o[3] - dt * 0.5 * (w[0] * o[0] + w[1] * o[1] + w[2] * o[2]);
+}
+static void quat_jac(const double* o, const double* w, double dt, double* F, int nz, int O0, int W0) {
+    const double Jo[16] = {0, -0.5 * w[2], 0.5 * w[1], 0.5 * w[0], 0.5 * w[2], 0, -0.5 * w[0], 0.5 * w[1],
+                           -0.5 * w[1], 0.5 * w[0], 0, 0.5 * w[2], -0.5 * w[0], -0.5 * w[1], -0.5 * w[2], 0};
+    const double Jw[12] = {0.5 * o[3], 0.5 * o[2], -0.5 * o[1], -0.5 * o[2], 0.5 * o[3], 0.5 * o[0],
+                           0.5 * o[1], -0.5 * o[0], 0.5 * o[3], -0.5 * o[0], -0.5 * o[1], -0.5 * o[2]};
+    for (int a = 0; a < 4; ++a) {
+        for (int b = 0; b < 4; ++b) F[(O0 + a) * nz + O0 + b] += dt * Jo[4 * a + b];
+        for (int b = 0; b < 3; ++b) F[(O0 + a) * nz + W0 + b] += dt * Jw[3 * a + b];
+    }
+}
+/* state residual rows of nodes 1..ns (prb.py:184-191; oracle/models.py _srbd_state_rows): 11 rows */
+static int srbd_state_rows(const consts_t* c, const double* x, int R0, int O0, int RD0, int W0, const double* rdot_ref, const double* w_ref,
+                           double otg, const double* q, double* r, double* J, int nz, int n) {
+    const double g = sqrt(c->w_rz);
+    r[n] = g * (x[R0 + 2] - c->com_z); if (J) J[n * nz + R0 + 2] = g; ++n;
+    const double* o = x + O0;
+    double oxq[3]; cross(o, q, oxq);
+    for (int a = 0; a < 3; ++a) r[n + a] = otg * (o[3] * q[a] + q[3] * o[a] + oxq[a]);
+    r[n + 3] = otg * (o[3] * q[3] - (o[0] * q[0] + o[1] * q[1] + o[2] * q[2]) - 1.0);
+    if (J) {
+        double Sq[9]; skew(q, Sq);
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) J[(n + a) * nz + O0 + b] = otg * ((a == b ? q[3] : 0.0) - Sq[3 * a + b]);
+            J[(n + a) * nz + O0 + 3] = otg * q[a];
+            J[(n + 3) * nz + O0 + a] = -otg * q[a];
+        }
+        J[(n + 3) * nz + O0 + 3] = otg * q[3];
+    }
+    n += 4;
+    const double gd = sqrt(c->w_rd), gw = sqrt(c->w_w);
+    for (int a = 0; a < 3; ++a) { r[n + a] = gd * (x[RD0 + a] - rdot_ref[a]); if (J) J[(n + a) * nz + RD0 + a] = gd; }
+    n += 3;
+    for (int a = 0; a < 3; ++a) { r[n + a] = gw * (x[W0 + a] - w_ref[a]); if (J) J[(n + a) * nz + W0 + a] = gw; }
+    return n + 3;
+}
+/* min_f_i, f_i_active (prb.py:202-204) and the optional friction-cone barrier rows; ucol = column of f in z = [x u] */
+static int force_rows(const consts_t* c, const double* f, double sw, int ucol, double* r, double* J, int nz, int n) {
+    const double g1 = sqrt(c->w_f), g2 = sqrt(c->w_sw) * (1.0 - sw);
+    for (int a = 0; a < 3; ++a) { r[n + a] = g1 * f[a]; if (J) J[(n + a) * nz + ucol + a] = g1; }
+    n += 3;
+    for (int a = 0; a < 3; ++a) { r[n + a] = g2 * f[a]; if (J) J[(n + a) * nz + ucol + a] = g2; }
+    n += 3;
+    if (c->bar_w > 0.0) {   /* r_j = sqrt(w) exp(s a_j.f / 2), rows of the linearised cone A f <= 0 */
+        const double ml = c->mu_lin;
+        const double A[5][3] = {{1, 0, -ml}, {-1, 0, -ml}, {0, 1, -ml}, {0, -1, -ml}, {0, 0, -1}};
+        for (int j = 0; j < 5; ++j) {
+            const double gj = A[j][0] * f[0] + A[j][1] * f[1] + A[j][2] * f[2];
+            const double rj = sqrt(c->bar_w) * exp(0.5 * c->bar_s * gj);
+            r[n + j] = rj;
+            if (J) for (int a = 0; a < 3; ++a) J[(n + j) * nz + ucol + a] = 0.5 * c->bar_s * rj * A[j][a];
+        }
+        n += 5;
+    }
+    return n;
+}
+/* rel_pos_{y,x}_1_4 and _3_6 (prb.py:192-199), d1 = p2 - p0, d2 = p3 - p1 (prb.py:153-154): 4 rows */
+static int rel_pos_rows(const consts_t* c, const double* x, const int* C0, double* r, double* J, int nz, int n) {
+    const double g = sqrt(c->w_rel);
+    const int pa[2] = {0, 1}, pb[2] = {2, 3};
+    for (int t = 0; t < 2; ++t) for (int e = 0; e < 2; ++e) {
+        const int comp = e == 0 ? 1 : 0, a = pa[t], b = pb[t];          /* y first, then x */
+        const double d = c->feet[3 * b + comp] - c->feet[3 * a + comp];
+        r[n] = g * (-x[C0[a] + comp] + x[C0[b] + comp] - d);
+        if (J) { J[n * nz + C0[a] + comp] = -g; J[n * nz + C0[b] + comp] = g; }
+        ++n;
+    }
+    return n;
+}
+/* equality constraints as sqrt(1e6)-weighted residuals (ddp.py:195-196; prb.py:166-170, :179-181), contact_model = 2: 16 rows */
+static int contact_penalty_rows(const double* x, const int* C0, const int* CD0, const double* cref, const double* sw, double* r, double* J,
+                                int nz, int n) {
+    const double g = sqrt(CW);
+    const int lead[2] = {0, 2}, foll[2] = {1, 3};
+    for (int t = 0; t < 2; ++t) {                                       /* relative_vel_left_1, relative_vel_right_3 */
+        for (int e = 0; e < 2; ++e) {
+            r[n + e] = g * (x[CD0[lead[t]] + e] - x[CD0[foll[t]] + e]);
+            if (J) { J[(n + e) * nz + CD0[lead[t]] + e] = g; J[(n + e) * nz + CD0[foll[t]] + e] = -g; }
+        }
+        n += 2;
+    }
+    for (int i = 0; i < 4; ++i) {
+        r[n] = g * (x[C0[i] + 2] - cref[i]); if (J) J[n * nz + C0[i] + 2] = g; ++n;                 /* cz_tracking_i */
+        for (int e = 0; e < 2; ++e) { r[n + e] = g * sw[i] * x[CD0[i] + e]; if (J) J[(n + e) * nz + CD0[i] + e] = g * sw[i]; }
+        n += 2;                                                                                      /* cdotxy_tracking_i */
+    }
+    return n;
 }
 
-static double forward(const consts_t* c, int N, const double* x0, const double* xs, const double* us, const double* P, const double* d,
-                      const double* K, const double* kff, double alpha, double* xn, double* un) {
-    memcpy(xn, x0, sizeof(double) * NX);
-    double J = 0;
-    for (int k = 0; k < N; ++k) {
-        double* x = xn + k * NX; double* u = un + k * NU;
-        for (int i = 0; i < NU; ++i) {
-            double s = us[k * NU + i] + alpha * kff[k * NU + i];
-            for (int j = 0; j < NX; ++j) s += K[((size_t)k * NU + i) * NX + j] * (x[j] - xs[k * NX + j]);
-            u[i] = s;
-        }
-        J += cost(c, x, u, P + k * NP, k);
-        dyn(c, x, u, P + k * NP, x + NX);
-        for (int i = 0; i < NX; ++i) x[NX + i] -= (1.0 - alpha) * d[k * NX + i];
-    }
-    return J + cost(c, xn + N * NX, NULL, P + N * NP, N);
+/* =================================================== srbd13 ===========================================================
+ * x = r|o|rdot|w, u = f_L|f_R, p = rdot_ref(3) | w_ref(3) | otg | oref(4) | cL(3) | cR(3) | swL | swR   */
+#define NX 13
+#define NU 6
+#define NP 19
+#define NR 39 /* residual rows of a stage node: 11 state + 18 input (+ 10 friction-cone barrier rows when enabled) */
+#define MDL(n) s13_##n
+static void s13_core(const consts_t* c, const double* x, const double* u, const double* p, core_t* k, corejac_t* J) {
+    const double* cs[2] = {p + 11, p + 14}; const double* fs[2] = {u, u + 3};
+    core_n(c, x, x + 3, x + 10, 2, cs, fs, k);
+    if (J) corejac_n(c, x, x + 3, x + 10, 2, cs, fs, k, J);
 }
-
-/* opts: max_iters, alpha_0, alpha_converge_threshold, factor, beta, cost_reduction_ths, mu0, initial_rollout, gap_tol, mu_min, mu_max, second_order
- * stats out: cost, iters, converged, alpha, gap, mu, status */
-int oracle_srbd13_solve(const double* cpack, int N, const double* x0, const double* P, double* xs, double* us, const double* o, double* stats) {
-    consts_t c; unpack_consts(cpack, &c);
-    const int max_iters = (int)o[0];
-    const double a0 = o[1], athr = o[2], fac = o[3], beta = o[4], ths = o[5], mu0 = o[6], gap_tol = o[8], mu_min = o[9], mu_max = o[10];
-    double* d = (double*)calloc((size_t)N * NX, sizeof(double));
-    double* K = (double*)malloc(sizeof(double) * (size_t)N * NU * NX);
-    double* kff = (double*)malloc(sizeof(double) * (size_t)N * NU);
-    double* xn = (double*)malloc(sizeof(double) * (size_t)(N + 1) * NX);
-    double* un = (double*)malloc(sizeof(double) * (size_t)N * NU);
-    if ((int)o[7]) { memcpy(xs, x0, sizeof(double) * NX); for (int k = 0; k < N; ++k) dyn(&c, xs + k * NX, us + k * NU, P + k * NP, xs + (k + 1) * NX); }
-    else {
-        memcpy(xs, x0, sizeof(double) * NX);
-        for (int k = 0; k < N; ++k) { double f[NX]; dyn(&c, xs + k * NX, us + k * NU, P + k * NP, f); for (int i = 0; i < NX; ++i) d[k * NX + i] = f[i] - xs[(k + 1) * NX + i]; }
+static void s13_dyn(const consts_t* c, const double* x, const double* u, const double* p, double* xn) {
+    core_t k; s13_core(c, x, u, p, &k, NULL);
+    const double dt = c->dt;
+    double on[4]; quat_step(x + 3, x + 10, dt, on);
+    for (int a = 0; a < 3; ++a) {
+        const double rd = x[7 + a], w = x[10 + a];
+        xn[a] = x[a] + dt * rd;
+        xn[7 + a] = rd + dt * k.rddot[a];
+        xn[10 + a] = w + dt * k.wdot[a];
     }
-    double J = total_cost(&c, N, xs, us, P), gap = 0;
-    for (int i = 0; i < N * NX; ++i) gap += fabs(d[i]);
-    double mu = mu0, rho = 0, alpha = 0, theta = 0;
-    const int second_order = (int)o[11];
-    int iters = 0, converged = 0, status = 1;
-    if (!isfinite(J)) status = 3;
-    else while (iters < max_iters) {
-        double sc[4]; int ok;
-        for (;;) {
-            ok = backward(&c, N, xs, us, P, d, mu, theta, K, kff, sc);
-            if (ok) break;
-            if (theta != 0.0) { theta = 0.0; continue; }
-            mu = fmax(mu, 0.0) * 10.0 + mu_min; if (mu > mu_max) break;
-        }
-        if (!ok) { status = 2; break; }
-        const double expected = -(sc[0] + sc[1]);
-        if (expected < ths && gap <= gap_tol) { converged = 1; status = 0; break; }
-        const double A1 = sc[0] + sc[2], B2 = sc[1] + sc[3];
-        if (gap > 0.0) rho = fmax(rho, 2.0 * fmax(fmax(A1, A1 + B2), 0.0) / gap);
-        const double slack = 1e-13 * (fabs(J) + rho * gap);
-        double a = a0, Jn = 0; int accepted = 0;
-        while (a >= athr) {
-            Jn = forward(&c, N, x0, xs, us, P, d, K, kff, a, xn, un);
-            const double pred = a * A1 + a * a * B2 - a * rho * gap;
-            const double dphi = (Jn + rho * (1.0 - a) * gap) - (J + rho * gap);
-            if (isfinite(Jn) && dphi <= beta * pred + slack) { accepted = 1; break; }
-            a *= fac;
-        }
-        if (!accepted) {
-            if (theta != 0.0) { theta = 0.0; continue; }
-            status = 4; converged = (gap <= gap_tol && expected <= ths * fmax(1.0, fabs(J))) ? 1 : 0; alpha = 0.0; break;
-        }
-        alpha = a;
-        theta = (second_order && a == a0) ? 1.0 : 0.0;
-        const double dJ = J - Jn;
-        memcpy(xs, xn, sizeof(double) * (size_t)(N + 1) * NX); memcpy(us, un, sizeof(double) * (size_t)N * NU);
-        J = Jn;
-        for (int i = 0; i < N * NX; ++i) d[i] *= (1.0 - a);
-        gap *= (1.0 - a);
-        ++iters;
-        if (mu > mu0) mu = fmax(mu0, mu * 0.1);
-        if (fabs(dJ) < ths && gap <= gap_tol) { converged = 1; status = 0; break; }
-    }
-    stats[0] = J; stats[1] = iters; stats[2] = converged; stats[3] = alpha; stats[4] = gap; stats[5] = mu; stats[6] = status;
-    free(d); free(K); free(kff); free(xn); free(un);
-    return 0;
+    for (int a = 0; a < 4; ++a) xn[3 + a] = on[a];
 }
+static void s13_wrows(const corejac_t* Jc, double g, double* M, int nz, int row0) {   /* rows of d wdot/dz scaled by g */
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) { M[(row0 + a) * nz + b] += g * Jc->Wr[3 * a + b]; M[(row0 + a) * nz + 10 + b] += g * Jc->Ww[3 * a + b]; }
+        for (int b = 0; b < 4; ++b) M[(row0 + a) * nz + 3 + b] += g * Jc->Wo[4 * a + b];
+        for (int i = 0; i < 2; ++i) for (int b = 0; b < 3; ++b) M[(row0 + a) * nz + 13 + 3 * i + b] += g * Jc->Wf[i][3 * a + b];
+    }
+}
+static void s13_dyn_jac(const consts_t* c, const double* x, const double* u, const double* p, double* F /*13x19*/) {
+    core_t k; corejac_t Jc; s13_core(c, x, u, p, &k, &Jc);
+    const double dt = c->dt; const int nz = 19;
+    memset(F, 0, sizeof(double) * 13 * nz);
+    for (int i = 0; i < 13; ++i) F[i * nz + i] = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        F[a * nz + 7 + a] += dt;
+        for (int i = 0; i < 2; ++i) F[(7 + a) * nz + 13 + 3 * i + a] = dt * c->inv_ms;
+    }
+    s13_wrows(&Jc, dt, F, nz, 10);
+    quat_jac(x + 3, x + 10, dt, F, nz, 3, 10);
+}
+static int s13_residual(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J) {
+    int n = 0; const int nz = 19;
+    if (J) memset(J, 0, sizeof(double) * NR * nz);
+    if (!u || k >= 1) n = srbd_state_rows(c, x, 0, 3, 7, 10, p, p + 3, p[6], p + 7, r, J, nz, n);
+    if (u) {
+        core_t kk; corejac_t Jc; s13_core(c, x, u, p, &kk, J ? &Jc : NULL);
+        const double g = sqrt(c->gq);
+        for (int a = 0; a < 3; ++a) { r[n + a] = g * kk.rddot[a]; r[n + 3 + a] = g * kk.wdot[a]; }
+        if (J) {
+            for (int a = 0; a < 3; ++a) for (int i = 0; i < 2; ++i) J[(n + a) * nz + 13 + 3 * i + a] = g * c->inv_ms;
+            s13_wrows(&Jc, g, J, nz, n + 3);
+        }
+        n += 6;
+        for (int i = 0; i < 2; ++i) n = force_rows(c, u + 3 * i, p[17 + i], 13 + 3 * i, r, J, nz, n);
+    }
+    return n;
+}
+/* exact bilinear-torque term: Qux[f_a][r_b] -= theta * s * skew(y)[a][b], y = I_w^-1 (dt v'_w)   */
+static void s13_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, double* Q) {
+    (void)u; (void)p;
+    double R[9], M[9], Mi[9], lam[3], y[3], S[9];
+    quat_to_rot(x + 3, R); world_inertia(c, R, M); inv3(M, Mi);
+    for (int a = 0; a < 3; ++a) lam[a] = c->dt * vp[10 + a];
+    mv3(Mi, lam, y); skew(y, S);
+    for (int i = 0; i < 2; ++i) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+        const double v = -theta * c->lever * S[3 * a + b];
+        Q[(13 + 3 * i + a) * 19 + b] += v; Q[b * 19 + 13 + 3 * i + a] += v;
+    }
+}
+#include "ddp_engine.inc"
+#undef NX
+#undef NU
+#undef NP
+#undef NR
+#undef MDL
 
-/* batch of independent instances; OpenMP over instances when compiled with -fopenmp */
+/* =================================================== srbd37 ===========================================================
+ * x = r | o | c0..c3 | rdot | w | cdot0..3 ; u = (cddot_i, f_i) x 4 interleaved (prb.py:32-68) ;
+ * p = rdot_ref | w_ref | otg | (c_ref_i, sw_i) x 4 | oref   */
+#define NX 37
+#define NU 24
+#define NP 19
+#define NR 96 /* 15 state + 18 min_qddot + 24 force (+ 20 barrier) + 16 penalty rows */
+#define MDL(n) s37_##n
+static const int S37_C[4] = {7, 10, 13, 16}, S37_CD[4] = {25, 28, 31, 34};
+static void s37_core(const consts_t* c, const double* x, const double* u, core_t* k, corejac_t* J) {
+    const double* cs[4] = {x + 7, x + 10, x + 13, x + 16}; const double* fs[4] = {u + 3, u + 9, u + 15, u + 21};
+    core_n(c, x, x + 3, x + 22, 4, cs, fs, k);
+    if (J) corejac_n(c, x, x + 3, x + 22, 4, cs, fs, k, J);
+}
+static void s37_dyn(const consts_t* c, const double* x, const double* u, const double* p, double* xn) {
+    (void)p;
+    core_t k; s37_core(c, x, u, &k, NULL);
+    const double dt = c->dt;
+    double on[4], tmp[37]; quat_step(x + 3, x + 22, dt, on);
+    for (int a = 0; a < 3; ++a) {
+        tmp[a] = x[a] + dt * x[19 + a];
+        tmp[19 + a] = x[19 + a] + dt * k.rddot[a];
+        tmp[22 + a] = x[22 + a] + dt * k.wdot[a];
+    }
+    for (int a = 0; a < 4; ++a) tmp[3 + a] = on[a];
+    for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) {
+        tmp[7 + 3 * i + a] = x[7 + 3 * i + a] + dt * x[25 + 3 * i + a];
+        tmp[25 + 3 * i + a] = x[25 + 3 * i + a] + dt * u[6 * i + a];
+    }
+    memcpy(xn, tmp, sizeof(tmp));
+}
+static void s37_wrows(const corejac_t* Jc, double g, double* M, int nz, int row0) {
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) { M[(row0 + a) * nz + b] += g * Jc->Wr[3 * a + b]; M[(row0 + a) * nz + 22 + b] += g * Jc->Ww[3 * a + b]; }
+        for (int b = 0; b < 4; ++b) M[(row0 + a) * nz + 3 + b] += g * Jc->Wo[4 * a + b];
+        for (int i = 0; i < 4; ++i) for (int b = 0; b < 3; ++b) {
+            M[(row0 + a) * nz + 7 + 3 * i + b] += g * Jc->Wc[i][3 * a + b];
+            M[(row0 + a) * nz + 37 + 6 * i + 3 + b] += g * Jc->Wf[i][3 * a + b];
+        }
+    }
+}
+static void s37_dyn_jac(const consts_t* c, const double* x, const double* u, const double* p, double* F /*37x61*/) {
+    (void)p;
+    core_t k; corejac_t Jc; s37_core(c, x, u, &k, &Jc);
+    const double dt = c->dt; const int nz = 61;
+    memset(F, 0, sizeof(double) * 37 * nz);
+    for (int i = 0; i < 37; ++i) F[i * nz + i] = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        F[a * nz + 19 + a] += dt;
+        for (int i = 0; i < 4; ++i) {
+            F[(19 + a) * nz + 37 + 6 * i + 3 + a] = dt * c->inv_ms;
+            F[(7 + 3 * i + a) * nz + 25 + 3 * i + a] += dt;
+            F[(25 + 3 * i + a) * nz + 37 + 6 * i + a] = dt;
+        }
+    }
+    s37_wrows(&Jc, dt, F, nz, 22);
+    quat_jac(x + 3, x + 22, dt, F, nz, 3, 22);
+}
+static int s37_residual(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J) {
+    int n = 0; const int nz = 61;
+    if (J) memset(J, 0, sizeof(double) * NR * nz);
+    if (!u || k >= 1) {
+        n = srbd_state_rows(c, x, 0, 3, 19, 22, p, p + 3, p[6], p + 15, r, J, nz, n);
+        n = rel_pos_rows(c, x, S37_C, r, J, nz, n);
+    }
+    if (u) {
+        core_t kk; corejac_t Jc; s37_core(c, x, u, &kk, J ? &Jc : NULL);
+        const double g = sqrt(c->gq);
+        for (int a = 0; a < 3; ++a) { r[n + a] = g * kk.rddot[a]; r[n + 3 + a] = g * kk.wdot[a]; }
+        for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) { r[n + 6 + 3 * i + a] = g * u[6 * i + a]; if (J) J[(n + 6 + 3 * i + a) * nz + 37 + 6 * i + a] = g; }
+        if (J) {
+            for (int a = 0; a < 3; ++a) for (int i = 0; i < 4; ++i) J[(n + a) * nz + 37 + 6 * i + 3 + a] = g * c->inv_ms;
+            s37_wrows(&Jc, g, J, nz, n + 3);
+        }
+        n += 18;
+        double cref[4], sw[4];
+        for (int i = 0; i < 4; ++i) { cref[i] = p[7 + 2 * i]; sw[i] = p[8 + 2 * i]; }
+        for (int i = 0; i < 4; ++i) n = force_rows(c, u + 6 * i + 3, sw[i], 37 + 6 * i + 3, r, J, nz, n);
+        n = contact_penalty_rows(x, S37_C, S37_CD, cref, sw, r, J, nz, n);
+    }
+    return n;
+}
+static void s37_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, double* Q) {
+    (void)u; (void)p;
+    double R[9], M[9], Mi[9], lam[3], y[3], S[9];
+    quat_to_rot(x + 3, R); world_inertia(c, R, M); inv3(M, Mi);
+    for (int a = 0; a < 3; ++a) lam[a] = c->dt * vp[22 + a];
+    mv3(Mi, lam, y); skew(y, S);
+    for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+        const double v = theta * c->lever * S[3 * a + b];
+        const int uf = 37 + 6 * i + 3 + a;
+        Q[uf * 61 + b] -= v; Q[b * 61 + uf] -= v;                               /* d2 / df dr */
+        Q[uf * 61 + 7 + 3 * i + b] += v; Q[(7 + 3 * i + b) * 61 + uf] += v;     /* d2 / df dc_i */
+    }
+}
+#include "ddp_engine.inc"
+#undef NX
+#undef NU
+#undef NP
+#undef NR
+#undef MDL
+
+/* ==================================================== lip30 ===========================================================
+ * x = r | c0..3 | rdot | cdot0..3 ; u = z | cddot0..3 ; p = rdot_ref | (c_ref_i, sw_i) x 4  (prb.py:248-441, App. A.5) */
+#define NX 30
+#define NU 15
+#define NP 11
+#define NR 48 /* 6 + 3 zmp + 4 rel_pos + 15 min_qddot + 16 penalty rows */
+#define MDL(n) l30_##n
+static const int L30_C[4] = {3, 6, 9, 12}, L30_CD[4] = {18, 21, 24, 27};
+static void l30_dyn(const consts_t* c, const double* x, const double* u, const double* p, double* xn) {
+    (void)p;
+    const double dt = c->dt, eta2 = GRAV / c->lip_h;
+    double tmp[30];
+    for (int i = 0; i < 15; ++i) tmp[i] = x[i] + dt * x[15 + i];
+    for (int a = 0; a < 3; ++a) tmp[15 + a] = x[15 + a] + dt * (eta2 * (x[a] - u[a]) - (a == 2 ? GRAV : 0.0));
+    for (int i = 0; i < 12; ++i) tmp[18 + i] = x[18 + i] + dt * u[3 + i];
+    memcpy(xn, tmp, sizeof(tmp));
+}
+static void l30_dyn_jac(const consts_t* c, const double* x, const double* u, const double* p, double* F /*30x45*/) {
+    (void)x; (void)u; (void)p;
+    const double dt = c->dt, eta2 = GRAV / c->lip_h; const int nz = 45;
+    memset(F, 0, sizeof(double) * 30 * nz);
+    for (int i = 0; i < 30; ++i) F[i * nz + i] = 1.0;
+    for (int i = 0; i < 15; ++i) F[i * nz + 15 + i] += dt;
+    for (int a = 0; a < 3; ++a) { F[(15 + a) * nz + a] += dt * eta2; F[(15 + a) * nz + 30 + a] = -dt * eta2; }
+    for (int i = 0; i < 12; ++i) F[(18 + i) * nz + 30 + 3 + i] = dt;
+}
+static int l30_residual(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J) {
+    int n = 0; const int nz = 45;
+    if (J) memset(J, 0, sizeof(double) * NR * nz);
+    double mean[3];
+    for (int a = 0; a < 3; ++a) mean[a] = 0.25 * (x[3 + a] + x[6 + a] + x[9 + a] + x[12 + a]);
+    const int state = !u || k >= 1;
+    if (state) {
+        const double g = sqrt(c->w_rz);
+        r[n] = g * (x[2] - c->com_z); if (J) J[n * nz + 2] = g; ++n;                         /* rz_tracking  prb.py:390 */
+        for (int e = 0; e < 2; ++e) {                                                          /* rxy_tracking prb.py:391 */
+            r[n + e] = g * (x[e] - mean[e]);
+            if (J) { J[(n + e) * nz + e] = g; for (int i = 0; i < 4; ++i) J[(n + e) * nz + L30_C[i] + e] = -0.25 * g; }
+        }
+        n += 2;
+        const double gd = sqrt(c->w_rd);
+        for (int a = 0; a < 3; ++a) { r[n + a] = gd * (x[15 + a] - p[a]); if (J) J[(n + a) * nz + 15 + a] = gd; }   /* prb.py:392 */
+        n += 3;
+    }
+    if (u) {
+        const double g = sqrt(c->w_zmp);                                                      /* zmp_tracking prb.py:393 */
+        for (int a = 0; a < 3; ++a) {
+            r[n + a] = g * (u[a] - mean[a]);
+            if (J) { J[(n + a) * nz + 30 + a] = g; for (int i = 0; i < 4; ++i) J[(n + a) * nz + L30_C[i] + a] = -0.25 * g; }
+        }
+        n += 3;
+    }
+    if (state) n = rel_pos_rows(c, x, L30_C, r, J, nz, n);                                    /* prb.py:394-401 */
+    if (u) {
+        const double eta2 = GRAV / c->lip_h, g = sqrt(c->gq);                                 /* min_qddot prb.py:402 */
+        for (int a = 0; a < 3; ++a) {
+            r[n + a] = g * (eta2 * (x[a] - u[a]) - (a == 2 ? GRAV : 0.0));
+            if (J) { J[(n + a) * nz + a] = g * eta2; J[(n + a) * nz + 30 + a] = -g * eta2; }
+        }
+        for (int i = 0; i < 12; ++i) { r[n + 3 + i] = g * u[3 + i]; if (J) J[(n + 3 + i) * nz + 33 + i] = g; }
+        n += 15;
+        double cref[4], sw[4];
+        for (int i = 0; i < 4; ++i) { cref[i] = p[3 + 2 * i]; sw[i] = p[4 + 2 * i]; }
+        n = contact_penalty_rows(x, L30_C, L30_CD, cref, sw, r, J, nz, n);
+    }
+    return n;
+}
+static void l30_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, double* Q) {
+    (void)c; (void)x; (void)u; (void)p; (void)vp; (void)theta; (void)Q;                      /* linear dynamics */
+}
+#include "ddp_engine.inc"
+#undef NX
+#undef NU
+#undef NP
+#undef NR
+#undef MDL
+
+/* ---- exported entry points: model 0 srbd13, 1 srbd37, 2 lip30 (ids of include/sddp.h) ------------------------------------ */
+int oracle_solve_batch(int model, const double* cpack, int N, int B, const double* x0, const double* P, double* xs, double* us,
+                       const double* o, double* stats, int threads) {
+    switch (model) {
+        case 0: return s13_solve_batch(cpack, N, B, x0, P, xs, us, o, stats, threads);
+        case 1: return s37_solve_batch(cpack, N, B, x0, P, xs, us, o, stats, threads);
+        case 2: return l30_solve_batch(cpack, N, B, x0, P, xs, us, o, stats, threads);
+    }
+    return -1;
+}
+int oracle_eval(int model, const double* cpack, const double* x, const double* u, const double* p, int k, int terminal,
+                double* f, double* F, double* H, double* g, double* L) {
+    switch (model) {
+        case 0: return s13_eval(cpack, x, u, p, k, terminal, f, F, H, g, L);
+        case 1: return s37_eval(cpack, x, u, p, k, terminal, f, F, H, g, L);
+        case 2: return l30_eval(cpack, x, u, p, k, terminal, f, F, H, g, L);
+    }
+    return -1;
+}
+/* kept names of the first version (srbd13 only) */
 int oracle_srbd13_solve_batch(const double* cpack, int N, int B, const double* x0, const double* P, double* xs, double* us,
                               const double* o, double* stats, int threads) {
-#ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
-#endif
-    for (int b = 0; b < B; ++b)
-        oracle_srbd13_solve(cpack, N, x0 + (size_t)b * NX, P + (size_t)b * (N + 1) * NP, xs + (size_t)b * (N + 1) * NX,
-                            us + (size_t)b * N * NU, o, stats + (size_t)b * 7);
-    return 0;
+    return s13_solve_batch(cpack, N, B, x0, P, xs, us, o, stats, threads);
 }
-
-/* per-knot evaluation for the cross-check against the numpy oracle: f[NX], F[NX*NZ], H[NZ*NZ], g[NZ], L */
 int oracle_srbd13_eval(const double* cpack, const double* x, const double* u, const double* p, int k, int terminal,
                        double* f, double* F, double* H, double* g, double* L) {
-    consts_t c; unpack_consts(cpack, &c);
-    if (!terminal) { dyn(&c, x, u, p, f); dyn_jac(&c, x, u, p, F); }
-    *L = cost_derivs(&c, x, terminal ? NULL : u, p, k, g, H);
-    return 0;
+    return s13_eval(cpack, x, u, p, k, terminal, f, F, H, g, L);
 }

@@ -1,21 +1,39 @@
-"""TEST INFRASTRUCTURE ONLY -- ctypes face of the plain-C oracle (oracle/c/sddp_oracle.c, built by oracle/Makefile)."""
+"""TEST INFRASTRUCTURE ONLY -- ctypes face of the plain-C oracle (oracle/c/sddp_oracle.c + ddp_engine.inc, built by oracle/Makefile)."""
 import ctypes as C
+import hashlib
 import os
 import subprocess
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+_SRC = [os.path.join(_HERE, "c", "sddp_oracle.c"), os.path.join(_HERE, "c", "ddp_engine.inc")]
 _lib = None
+
+MODEL_IDS = {"srbd13": 0, "srbd37": 1, "lip30": 2}
+DIMS = {"srbd13": (13, 6, 19), "srbd37": (37, 24, 19), "lip30": (30, 15, 11)}
+
+
+def _host_tag():
+    """The library is compiled with -march=native: one build per CPU type (a build from another machine may not run here)."""
+    try:
+        flags = [l for l in open("/proc/cpuinfo") if l.startswith(("flags", "model name"))][:2]
+    except OSError:
+        flags = []
+    return hashlib.sha1("".join(flags).encode()).hexdigest()[:10]
+
+
+def lib_path():
+    return os.path.join(_HERE, "_build", f"liboracle-{_host_tag()}.so")
 
 
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "c", "sddp_oracle.c")):
-            subprocess.run(["make", "-C", _HERE, "-s"], check=True)
-        _lib = C.CDLL(_LIB)
+        path = lib_path()
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in _SRC):
+            subprocess.run(["make", "-C", _HERE, "-s", f"LIB={os.path.relpath(path, _HERE)}"], check=True)
+        _lib = C.CDLL(path)
     return _lib
 
 
@@ -24,7 +42,9 @@ def pack_consts(cst):
     return np.array([cst.m, *np.asarray(cst.I, dtype=float).reshape(-1), cst.com[2], cst.dt, cst.force_scaling,
                      cst.r_tracking_gain, cst.rdot_tracking_gain, cst.w_tracking_gain, cst.force_switch_weight,
                      cst.min_qddot_gain, cst.min_f_gain, float(cst.inertia_mode), cst.lever_sign,
-                     cst.friction_cone_coefficient, cst.friction_barrier_weight, cst.friction_barrier_sharpness], dtype=np.float64)
+                     cst.friction_cone_coefficient, cst.friction_barrier_weight, cst.friction_barrier_sharpness,
+                     cst.rel_pos_gain, cst.zmp_tracking_gain, cst.lip_height, *np.asarray(cst.feet, dtype=float).reshape(-1)],
+                    dtype=np.float64)
 
 
 def pack_opts(o):
@@ -38,24 +58,32 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def solve_batch(cst, opts, x0, P, xs, us, threads=1):
-    """-> xs [B,N+1,13], us [B,N,6], stats [B,7] = cost, iters, converged, alpha, gap, mu, status"""
+def solve_batch(cst, opts, x0, P, xs, us, threads=1, model="srbd13"):
+    """-> xs [B,N+1,nx], us [B,N,nu], stats [B,7] = cost, iters, converged, alpha, gap, mu, status"""
     lib = load()
     B, N = us.shape[0], us.shape[1]
+    nx, nu, npar = DIMS[model]
     xs = np.ascontiguousarray(xs, dtype=np.float64).copy()
     us = np.ascontiguousarray(us, dtype=np.float64).copy()
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     P = np.ascontiguousarray(P, dtype=np.float64)
+    assert xs.shape == (B, N + 1, nx) and us.shape == (B, N, nu) and x0.shape == (B, nx) and P.shape == (B, N + 1, npar)
     stats = np.zeros((B, 7))
     cp, op = pack_consts(cst), pack_opts(opts)
-    lib.oracle_srbd13_solve_batch(_p(cp), C.c_int(N), C.c_int(B), _p(x0), _p(P), _p(xs), _p(us), _p(op), _p(stats), C.c_int(threads))
+    rc = lib.oracle_solve_batch(C.c_int(MODEL_IDS[model]), _p(cp), C.c_int(N), C.c_int(B), _p(x0), _p(P), _p(xs), _p(us), _p(op),
+                                _p(stats), C.c_int(threads))
+    assert rc == 0
     return xs, us, stats
 
 
-def eval_knot(cst, x, u, p, k, terminal):
+def eval_knot(cst, x, u, p, k, terminal, model="srbd13"):
     lib = load()
-    f = np.zeros(13); F = np.zeros((13, 19)); H = np.zeros((19, 19)); g = np.zeros(19); L = np.zeros(1)
+    nx, nu, _ = DIMS[model]
+    nz = nx + nu
+    f = np.zeros(nx); F = np.zeros((nx, nz)); H = np.zeros((nz, nz)); g = np.zeros(nz); L = np.zeros(1)
     cp = pack_consts(cst)
     x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64)
-    lib.oracle_srbd13_eval(_p(cp), _p(x), _p(u), _p(p), C.c_int(k), C.c_int(int(terminal)), _p(f), _p(F), _p(H), _p(g), _p(L))
+    rc = lib.oracle_eval(C.c_int(MODEL_IDS[model]), _p(cp), _p(x), _p(u), _p(p), C.c_int(k), C.c_int(int(terminal)), _p(f), _p(F), _p(H),
+                         _p(g), _p(L))
+    assert rc == 0
     return f, F, H, g, float(L[0])

@@ -64,3 +64,41 @@ def test_exhausted_line_search_is_a_stall_not_convergence_in_both_oracles():
     r2 = oddp.solve(m, batch["x0"][0], batch["params"][0], opt.xs, opt.us, hard)
     _, _, st2 = cport.solve_batch(cst, hard, batch["x0"], batch["params"], opt.xs[None], opt.us[None])
     assert r2.status in (0, 4) and r2.converged and int(st2[0, 2]) == 1 and int(st2[0, 6]) == r2.status
+
+
+@pytest.mark.parametrize("name,barrier", [("srbd37", 0.0), ("srbd37", 6.0), ("lip30", 0.0)])
+def test_c_knot_evaluation_matches_numpy_reference_models(name, barrier):
+    cst = omodels.RobotConsts(friction_barrier_weight=barrier, friction_barrier_sharpness=4.0)
+    m = omodels.make_model(name, cst)
+    rng = np.random.default_rng(5)
+    for k, term in ((0, False), (3, False), (20, True)):
+        x = m.initial_state() + 0.05 * rng.standard_normal(m.nx)
+        u = m.static_input() + 0.05 * rng.standard_normal(m.nu)
+        p = m.default_params(20)[3] + 0.05 * rng.standard_normal(m.np_)
+        f, F, H, g, L = cport.eval_knot(cst, x, u, p, k, term, model=name)
+        Lo, lx, lu, lxx, lux, luu = m.cost_derivs(x, None if term else u, p, k)
+        assert abs(L - Lo) <= 1e-12 * max(1, abs(Lo))
+        nx = m.nx
+        if term:
+            np.testing.assert_allclose(g[:nx], lx, rtol=1e-11, atol=1e-9 * max(1, np.max(np.abs(lx))))
+            np.testing.assert_allclose(H[:nx, :nx], lxx, rtol=1e-11, atol=1e-7)
+        else:
+            np.testing.assert_allclose(f, m.f(x, u, p), rtol=1e-12, atol=1e-13)
+            fx, fu = m.f_jac(x, u, p)
+            np.testing.assert_allclose(F, np.hstack([fx, fu]), rtol=1e-11, atol=1e-12)
+            np.testing.assert_allclose(g, np.concatenate([lx, lu]), rtol=1e-11, atol=1e-9 * max(1, np.max(np.abs(g))))
+            np.testing.assert_allclose(H, np.block([[lxx, lux.T], [lux, luu]]), rtol=1e-11, atol=1e-9 * np.max(np.abs(H)))
+
+
+@pytest.mark.parametrize("name,N,seeds", [("srbd37", 20, [0, 3]), ("lip30", 20, [1, 2]), ("srbd37", 8, [5])])
+def test_c_solve_matches_numpy_solve_reference_models(name, N, seeds):
+    batch = workload.make_batch(name, N, seeds)
+    cst = omodels.RobotConsts()
+    m = omodels.make_model(name, cst)
+    opts = oddp.DdpOptions(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
+    xs, us, st = cport.solve_batch(cst, opts, batch["x0"], batch["params"], batch["xs"], batch["us"], threads=2, model=name)
+    for b in range(len(seeds)):
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], opts)
+        assert int(st[b, 1]) == r.iters and bool(st[b, 2]) == r.converged and st[b, 3] == r.alpha and int(st[b, 6]) == r.status
+        assert np.max(np.abs(xs[b] - r.xs)) <= 1e-7 and np.max(np.abs(us[b] - r.us)) <= 1e-7
+        assert abs(st[b, 0] - r.cost) <= 1e-9 * abs(r.cost)
