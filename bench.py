@@ -93,6 +93,24 @@ def cpu_baseline(N, B, budget_s=12.0):
                       f"host has {os.cpu_count()} cores"}
 
 
+def cpu_tick_baseline(model, trace, gpu_iters):
+    """The recorded solver inputs of a receding-horizon run (mpc.MpcLoop.trace: x0, params, warm start of every tick) solved one
+    by one by the plain-C oracle on ONE host thread: the CPU figure beside ms/MPC-tick (the reference's metric, the tic/toc
+    around solver.solve() at dsrbd_example.py:134-136)."""
+    from oracle import cport, ddp as oddp, models as omodels
+    cst = omodels.RobotConsts()
+    opts = oddp.DdpOptions(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
+    ms, its = [], []
+    for t in trace:
+        t1 = time.perf_counter()
+        _, _, st = cport.solve_batch(cst, opts, t["x0"][None], t["params"][None], t["xs"][None], t["us"][None], threads=1, model=model)
+        ms.append(1e3 * (time.perf_counter() - t1))
+        its.append(int(st[0, 1]))
+    return {"solve_median": float(np.median(ms)), "solve_p99": float(np.percentile(ms, 99)), "mean_iters": float(np.mean(its)),
+            "same_iters_as_gpu_frac": float(np.mean(np.asarray(its) == np.asarray(gpu_iters))), "cores": 1, "kind": "port",
+            "sample": f"{len(trace)} recorded ticks, each solved from the same x0 / parameters / warm start as the GPU tick"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,6 +305,14 @@ def single_instance_extras(N, opts, workload, DdpEngine):
     # ms / MPC tick as SURVEY 8(d) defines it: receding-horizon loop (param shift + pack + solve + unpack + simulate),
     # B = 1, warm-started from the previous tick, walking with a forward command; 20 warm-up + 200 timed ticks
     from srbd_horizon_amd.mpc import MpcLoop
+    def traced(model, ns, ticks):
+        """the same (deterministic) loop once more, untimed, recording every tick's solver inputs for the CPU replay"""
+        lp = MpcLoop(model, ns, warm_start="device")
+        lp.trace = []
+        for _ in range(ticks):
+            lp.tick("walking", (1.0, 0.0))
+        return lp.trace
+
     loop = MpcLoop("srbd13", N, warm_start="device")
     tick_ms, its = [], []
     for i in range(220):
@@ -296,6 +322,7 @@ def single_instance_extras(N, opts, workload, DdpEngine):
         its.append(int(loop.solver.stats["iters"]))
     out["ms_per_mpc_tick"] = {"median": float(np.median(tick_ms[20:])), "p99": float(np.percentile(tick_ms[20:], 99)),
                               "solve_median": float(np.median(loop.solve_ms[20:])), "mean_iters": float(np.mean(its[20:])),
+                              "cpu": cpu_tick_baseline("srbd13", traced("srbd13", N, 220)[20:], its[20:]),
                               "note": "srbd13 receding-horizon loop (mpc.MpcLoop = dsrbd_example.py:82-185 without ROS), B=1, "
                                       "N=30, walking forward, warm start = previous solution, 200 ticks after 20 warm-up; "
                                       "tick = host scheduler + sddp_advance (device-side shift of parameters and warm start; last "
@@ -303,17 +330,34 @@ def single_instance_extras(N, opts, workload, DdpEngine):
     # the reference's own example loops (its real problem sizes, ns = 20, T = 1 s): dsrbd_example.py (srbd37) and
     # dlip_example.py (lip30, configs[0]); 10 warm-up + 100 timed ticks each
     out["ms_per_mpc_tick_reference_models"] = {}
-    for mname in ("srbd37", "lip30"):
-        lp = MpcLoop(mname, 20, warm_start="device")
+    for mname, ns in (("srbd37", 20), ("lip30", 20), ("srbd37", 60)):
+        lp = MpcLoop(mname, ns, warm_start="device")
         tms, its = [], []
-        for i in range(110):
+        nt = 110 if ns == 20 else 60
+        for i in range(nt):
             t1 = time.perf_counter()
             lp.tick("walking", (1.0, 0.0))
             tms.append(1e3 * (time.perf_counter() - t1))
             its.append(int(lp.solver.stats["iters"]))
-        out["ms_per_mpc_tick_reference_models"][mname] = {
+        out["ms_per_mpc_tick_reference_models"][mname + ("" if ns == 20 else f"_n{ns}")] = {
             "median": float(np.median(tms[10:])), "p99": float(np.percentile(tms[10:], 99)),
-            "solve_median": float(np.median(lp.solve_ms[10:])), "mean_iters": float(np.mean(its[10:]))}
+            "solve_median": float(np.median(lp.solve_ms[10:])), "mean_iters": float(np.mean(its[10:])),
+            "cpu": cpu_tick_baseline(mname, traced(mname, ns, nt)[10:], its[10:])}
+    # BASELINE configs[4] as a batch: srbd37, N = 60, multiple shooting from a cold start with open defects, one launch
+    # (4 wavefronts per instance, one instance per CU resident: 256 slots, the rest queue)
+    B5 = 512
+    b5 = workload.make_batch("srbd37", 60, np.arange(B5))
+    e5 = DdpEngine("srbd37", 60, B5, opts=opts)
+    t5 = []
+    for _ in range(3):
+        e5.set_initial_state(b5["x0"]); e5.set_x_warmstart(b5["xs"]); e5.set_u_warmstart(b5["us"])
+        e5.set_params(b5["params"]); e5.synchronize()
+        t1 = time.perf_counter()
+        e5.solve_resident()
+        t5.append(time.perf_counter() - t1)
+    out["srbd37_n60_batch"] = {"solves_per_s": B5 / min(t5), "batch": B5, "mean_iters": float(np.mean(e5.stats["iters"])),
+                               "converged_frac": float(np.mean(e5.stats["converged"] == 1)), "slots": e5.queue_info()[0],
+                               "note": "configs[4]: srbd37 N=60 cold start, host-pointer result fetch included"}
     return out
 
 

@@ -25,7 +25,38 @@ from .problem import Problem
 # option keys the reference forwards to pyddp.DdpSolverOptions (ddp.py:16-35) + engine extras
 _REFERENCE_KEYS = ("max_iters", "alpha_0", "alpha_converge_threshold", "line_search_decrease_factor", "beta",
                    "cost_reduction_ths", "mu0")
-_EXTRA_KEYS = ("initial_rollout", "gap_tol", "mu_min", "mu_max", "second_order", "waves_per_simd")
+_EXTRA_KEYS = ("initial_rollout", "gap_tol", "mu_min", "mu_max", "second_order", "waves_per_simd", "queue_order")
+
+# What each registered analytic model implements, by the reference's function names (prb.py:166-204, :379-402):
+#   cost:  name -> (model constant that carries its gain or None, "state" = nodes 1..ns | "stage" = nodes 0..ns-1)
+#   eq:    equality constraints hard-wired as sqrt(1e6)-weighted penalty rows on nodes 0..ns-1 (ddp.py:195-196, :216-226)
+#   ineq:  inequality constraints available as an opt-in barrier (the reference ignores them, ddp.py:197-202)
+def _srbd_terms(nc, contact_states):
+    cost = {"rz_tracking": ("r_tracking_gain", "state"), "o_tracking_xyz": (None, "state"), "o_tracking_w": (None, "state"),
+            "rdot_tracking": ("rdot_tracking_gain", "state"), "w_tracking": ("w_tracking_gain", "state"),
+            "min_qddot": ("min_qddot_gain", "stage")}
+    eq = []
+    if contact_states:
+        for nm in ("rel_pos_y_1_4", "rel_pos_x_1_4", "rel_pos_y_3_6", "rel_pos_x_3_6"):
+            cost[nm] = ("rel_pos_gain", "state")
+        eq = ["relative_vel_left_1", "relative_vel_right_3"] + [f"{t}{i}" for i in range(nc) for t in ("cz_tracking", "cdotxy_tracking")]
+    for i in range(nc):
+        cost[f"min_f{i}"] = ("min_f_gain", "stage")
+        cost[f"f{i}_active"] = ("force_switch_weight", "stage")
+    return dict(cost=cost, eq=eq, ineq=[f"f{i}_friction_cone" for i in range(nc)])
+
+
+MODEL_TERMS = {
+    "srbd37": _srbd_terms(4, True),
+    "srbd13": _srbd_terms(2, False),
+    "lip30": dict(cost={"rz_tracking": ("r_tracking_gain", "state"), "rxy_tracking": ("r_tracking_gain", "state"),
+                        "rdot_tracking": ("rdot_tracking_gain", "state"), "zmp_tracking": ("zmp_tracking_gain", "stage"),
+                        "rel_pos_y_1_4": ("rel_pos_gain", "state"), "rel_pos_x_1_4": ("rel_pos_gain", "state"),
+                        "rel_pos_y_3_6": ("rel_pos_gain", "state"), "rel_pos_x_3_6": ("rel_pos_gain", "state"),
+                        "min_qddot": ("min_qddot_gain", "stage")},
+                  eq=["relative_vel_left_1", "relative_vel_right_3"] + [f"{t}{i}" for i in range(4) for t in ("cz_tracking", "cdotxy_tracking")],
+                  ineq=[]),
+}
 
 
 class DDPSolver:
@@ -42,7 +73,8 @@ class DDPSolver:
         self.input_var = prb.getInput().getVars()
         self.input_size = sum(v.getDim() for v in self.input_var)
         self.param_var = prb.getParameters()
-        consts = dict(prb.model_consts)
+        self._collect_constraints()
+        consts = self._model_consts_from_functions()
         if prb.getDt() is not None:
             consts["dt"] = prb.getDt()
         self.ddp_solver = DdpEngine(prb.model, prb.nodes - 1, 1, opts=self.opts, consts=consts)
@@ -127,6 +159,63 @@ class DDPSolver:
         upper = np.array(constr.getUpperBounds())
         lower = np.array(constr.getLowerBounds())
         return np.linalg.norm(upper - lower) <= 1e-6
+
+    def _collect_constraints(self):
+        """ddp.py:38-48: equality constraints (coincident bounds) apart from inequality constraints."""
+        self.var_container = self.prb.var_container
+        self.fun_container = self.prb.function_container
+        self.equality_constraints = []
+        self.inequality_constraints = []
+        for constr in self.fun_container.getCnstr().values():
+            if self.is_equality_constraint(constr):
+                self.equality_constraints.append(constr)
+            else:
+                self.inequality_constraints.append(constr)
+
+    def _model_consts_from_functions(self):
+        """Constants of the registered model from the problem's cost terms and constraints -- the counterpart of get_L /
+        get_L_term (ddp.py:179-226), which sum whatever the function container holds.  A declared residual sets the gain of
+        its term (removing it switches the term off); equality constraints must be exactly the penalties the model hard-wires;
+        inequality constraints are ignored like the reference ignores them (ddp.py:197-202 is commented out) unless the model's
+        opt-in barrier is on.  Anything the analytic model cannot express raises instead of being silently dropped."""
+        prb = self.prb
+        consts = dict(prb.model_consts)
+        table = MODEL_TERMS[prb.model]
+        ns = prb.nodes - 1
+        ranges = {"state": list(range(1, ns + 1)), "stage": list(range(0, ns))}
+        cost = self.fun_container.getCost()
+        if not cost and not self.fun_container.getCnstr():
+            return consts                                       # a problem without declarations: the model's built-in defaults
+        unknown = [n for n in cost if n not in table["cost"]]
+        if unknown:
+            raise NotImplementedError(f"model {prb.model} has no analytic term for residual(s) {unknown}")
+        gains = {}
+        for name, (ckey, kind) in table["cost"].items():
+            fn = cost.get(name)
+            if fn is None:
+                if ckey is None:
+                    raise NotImplementedError(f"residual {name!r} cannot be removed from model {prb.model} (its weight is the "
+                                              "orientation_tracking_gain parameter: assign 0 to switch it off)")
+                gains.setdefault(ckey, []).append(0.0)
+                continue
+            if fn.getNodes() != ranges[kind]:
+                raise NotImplementedError(f"residual {name!r}: model {prb.model} implements it on nodes {ranges[kind][0]}..{ranges[kind][-1]} only")
+            if ckey is not None:
+                gains.setdefault(ckey, []).append(float(fn.term.gain))
+        for ckey, vals in gains.items():
+            if len(set(vals)) != 1:
+                raise NotImplementedError(f"model {prb.model} has ONE gain {ckey} for {len(vals)} residuals; got {sorted(set(vals))}")
+            consts[ckey] = vals[0]
+        eq_names = [c.getName() for c in self.equality_constraints]
+        if sorted(eq_names) != sorted(table["eq"]):
+            raise NotImplementedError(f"model {prb.model} hard-wires the equality constraints {table['eq']}; the problem holds {eq_names}")
+        for c in self.equality_constraints:
+            if c.getNodes() != list(range(0, ns + 1)):
+                raise NotImplementedError(f"constraint {c.getName()!r}: only the default node range is implemented")
+        bad = [c.getName() for c in self.inequality_constraints if c.getName() not in table["ineq"]]
+        if bad:
+            raise NotImplementedError(f"model {prb.model} has no barrier for inequality constraint(s) {bad}")
+        return consts
 
     def _createVarSolDict(self, x, u):
         """ddp.py:125-151: walk the variables in creation order; states first, then inputs."""

@@ -61,6 +61,8 @@ class MpcLoop:
         self.solver.set_x_warmstart(np.repeat(self.state[:, None], ns + 1, axis=1))
         self.solver.set_u_warmstart(np.repeat(self.srbd.getStaticInput()[:, None], ns, axis=1))
         self.solve_ms = []
+        self.trace = None          # set to a list to record every tick's solver inputs (x0, params, warm start): bench.py replays them
+        self._last = None
 
     def tick(self, motion: str = "standing", axes=(0.0, 0.0)):
         s, ns = self.srbd, self.ns
@@ -72,6 +74,8 @@ class MpcLoop:
         a = 0.1 if motion == "standing" else 0.5                                       # :109-112
         s.rdot_ref.assign([a * axes[0], a * axes[1], 0.0], nodes=ns)                   # :119-122
         self.wpg.set({"walking": "step", "jumping": "jump"}.get(motion, "standing"))   # :126-131
+        if self.trace is not None:
+            self.trace.append(self._solver_inputs())
         t0 = time.perf_counter()                                                       # :134 tic()
         if self.warm_start == "device":
             converged = self.solver.solve_receding(self.state)                         # :84 + :135, device-resident data
@@ -79,6 +83,7 @@ class MpcLoop:
             converged = self.solver.solve()                                            # :135
         self.solve_ms.append(1e3 * (time.perf_counter() - t0))                         # :136 toc()
         sol = self.solver.getSolutionDict()                                            # :137
+        self._last = sol
         u0 = sol["u_opt"][:, 0]                                                        # :158
         p0 = s.prb.parameter_matrix()[0]
         self.state = self.solver.ddp_solver.model_step(self.state[None], u0[None], p0[None], 0)[0]   # :159 Euler step (same HIP model)
@@ -92,6 +97,21 @@ class MpcLoop:
             self.solver.set_x_warmstart(np.repeat(self.state[:, None], ns + 1, axis=1))
             self.solver.set_u_warmstart(np.repeat(s.getStaticInput()[:, None], ns, axis=1))
         return converged, sol
+
+    def _solver_inputs(self):
+        """What this tick's solve starts from, in the C ABI's knot-major layout (warm_start "device" / "shift": the previous
+        solution advanced by one knot, last knot repeated; first tick: state at every node, static input)."""
+        ns = self.ns
+        if self._last is None or self.warm_start == "reset":
+            xs = np.repeat(self.state[None, :], ns + 1, axis=0)
+            us = np.repeat(self.srbd.getStaticInput()[None, :], ns, axis=0)
+        elif self.warm_start == "previous":
+            xs, us = self._last["x_opt"].T.copy(), self._last["u_opt"].T.copy()
+        else:
+            x, u = self._last["x_opt"], self._last["u_opt"]
+            xs = np.concatenate([x[:, 1:], x[:, -1:]], axis=1).T.copy()
+            us = np.concatenate([u[:, 1:], u[:, -1:]], axis=1).T.copy()
+        return dict(x0=self.state.copy(), params=self.srbd.prb.parameter_matrix().copy(), xs=xs, us=us)
 
     def reference_record(self, sol, node: int = 1, foot_frames=("left_sole_link", "right_sole_link")):
         """ROS-free form of what the reference hands to CartesIO every tick (cartesio.py:58-79, called at

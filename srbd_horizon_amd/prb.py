@@ -16,7 +16,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .problem import Aggregate, ParameterRow, Problem
+from .problem import Aggregate, ParameterRow, Problem, Term
 
 
 @dataclass
@@ -57,6 +57,45 @@ def _consts(robot: RobotModel, prm: dict, dt: float, feet) -> dict:
                 friction_barrier_sharpness=float(prm["friction_barrier_sharpness"]))
 
 
+def _declare_srbd_terms(prb, prm, ns, nc, contact_model, with_contact_states: bool):
+    """The cost terms and constraints of prb.py:166-204, declared in the reference's order with its names and node ranges.
+    `with_contact_states`: the reference problem (contacts are states); False: the metric model (contacts are parameters, so
+    the contact penalties and rel_pos terms do not exist)."""
+    if with_contact_states:
+        if contact_model > 1:                                                             # prb.py:166-170
+            for i in range(1, contact_model):
+                prb.createConstraint("relative_vel_left_" + str(i), Term("relative_vel", dim=2))
+            for i in range(contact_model + 1, 2 * contact_model):
+                prb.createConstraint("relative_vel_right_" + str(i), Term("relative_vel", dim=2))
+    if prm["friction_barrier_weight"] > 0.0:
+        # prb.py:172-177 builds the linearised friction cone per contact force and leaves its createIntermediateConstraint
+        # commented out, so the reference's container never holds it.  It is declared (as the inequality A f <= 0 it is) only when
+        # this build's opt-in barrier is switched on; the adapter then finds it among the inequality constraints (ddp.py:46-48)
+        for i in range(nc):
+            prb.createIntermediateConstraint(f"f{i}_friction_cone", Term("friction_cone", "friction_cone_coefficient",
+                                                                        prm["friction_cone_coefficient"], dim=5),
+                                             bounds=dict(lb=-np.inf, ub=0.0))
+    if with_contact_states:
+        for i in range(nc):                                                               # prb.py:179-181
+            prb.createConstraint("cz_tracking" + str(i), Term("cz_tracking"))
+            prb.createConstraint("cdotxy_tracking" + str(i), Term("cdotxy_tracking", dim=2))
+    st = range(1, ns + 1)
+    prb.createResidual("rz_tracking", Term("rz_tracking", "r_tracking_gain", prm["r_tracking_gain"]), nodes=st)          # :184
+    prb.createResidual("o_tracking_xyz", Term("o_tracking", dim=3), nodes=st)                                              # :188
+    prb.createResidual("o_tracking_w", Term("o_tracking"), nodes=st)                                                       # :189
+    prb.createResidual("rdot_tracking", Term("rdot_tracking", "rdot_tracking_gain", prm["rdot_tracking_gain"], 3), nodes=st)   # :190
+    prb.createResidual("w_tracking", Term("w_tracking", "w_tracking_gain", prm["w_tracking_gain"], 3), nodes=st)          # :191
+    if with_contact_states:
+        for nm in ("rel_pos_y_1_4", "rel_pos_x_1_4", "rel_pos_y_3_6", "rel_pos_x_3_6"):                                   # :192-199
+            prb.createResidual(nm, Term("rel_pos", "rel_pos_gain", prm["rel_position_gain"]), nodes=st)
+    prb.createResidual("min_qddot", Term("min_qddot", "min_qddot_gain", prm["min_qddot_gain"], 6 + (3 * nc if with_contact_states else 0)),
+                       nodes=range(0, ns))                                                                                 # :200
+    for i in range(nc):                                                                                                    # :201-204
+        prb.createResidual("min_f" + str(i), Term("min_f", "min_f_gain", prm["min_f_gain"], 3), nodes=range(0, ns))
+        prb.createResidual("f" + str(i) + "_active", Term("f_active", "force_switch_weight", prm["force_switch_weight"], 3),
+                           nodes=range(0, ns))
+
+
 class SRBDProblem:
     """prb.py:16-246 -- nx = 37, nu = 24, np = 19 with the launch file's contact_model=2, number_of_legs=2."""
 
@@ -93,6 +132,7 @@ class SRBDProblem:
             cdot_switch[i].assign(1.0, nodes=range(0, ns + 1))
         oref = prb.createParameter("oref", 4)                                 # prb.py:185
         oref.assign(quat_inverse(np.array([0.0, 0.0, 0.0, 1.0])))             # prb.py:186
+        _declare_srbd_terms(prb, prm, ns, nc, contact_model, True)            # prb.py:166-204
         prb.setModel("srbd37", _consts(robot, prm, T / ns, feet))
         self.prb = prb
         self.initial_foot_position = {i: feet[i].copy() for i in range(nc)}
@@ -144,6 +184,7 @@ class SRBD13Problem:
             cdot_switch[i] = prb.createParameter("cdot_switch" + str(i), 1)
             cdot_switch[i].assign(1.0)
         prb.setDt(T / ns)
+        _declare_srbd_terms(prb, prm, ns, 2, 1, False)
         prb.setModel("srbd13", _consts(robot, prm, T / ns, feet4))
         self.prb = prb
         self.initial_foot_position = {i: centers[i].copy() for i in range(2)}
@@ -191,6 +232,22 @@ class LIPProblem:
             c_ref[i].assign(feet[i][2], nodes=range(0, ns + 1))
             cdot_switch[i] = prb.createParameter("cdot_switch" + str(i), 1)
             cdot_switch[i].assign(1.0, nodes=range(0, ns + 1))
+        # prb.py:379-402, in the reference's order
+        for i in range(1, contact_model):
+            prb.createConstraint("relative_vel_left_" + str(i), Term("relative_vel", dim=2))
+        for i in range(contact_model + 1, 2 * contact_model):
+            prb.createConstraint("relative_vel_right_" + str(i), Term("relative_vel", dim=2))
+        for i in range(nc):
+            prb.createConstraint("cz_tracking" + str(i), Term("cz_tracking"))
+            prb.createConstraint("cdotxy_tracking" + str(i), Term("cdotxy_tracking", dim=2))
+        st = range(1, ns + 1)
+        prb.createResidual("rz_tracking", Term("rz_tracking", "r_tracking_gain", prm["r_tracking_gain"]), nodes=st)          # :390
+        prb.createResidual("rxy_tracking", Term("rxy_tracking", "r_tracking_gain", prm["r_tracking_gain"], 2), nodes=st)     # :391
+        prb.createResidual("rdot_tracking", Term("rdot_tracking", "rdot_tracking_gain", prm["rdot_tracking_gain"], 3), nodes=st)   # :392
+        prb.createResidual("zmp_tracking", Term("zmp_tracking", "zmp_tracking_gain", prm["zmp_tracking_gain"], 3), nodes=range(0, ns))   # :393
+        for nm in ("rel_pos_y_1_4", "rel_pos_x_1_4", "rel_pos_y_3_6", "rel_pos_x_3_6"):                                      # :394-401
+            prb.createResidual(nm, Term("rel_pos", "rel_pos_gain", prm["rel_position_gain"]), nodes=st)
+        prb.createResidual("min_qddot", Term("min_qddot", "min_qddot_gain", prm["min_qddot_gain"], 15), nodes=range(0, ns))  # :402
         prb.setModel("lip30", _consts(robot, prm, T / ns, feet))
         self.prb = prb
         self.initial_foot_position = {i: feet[i].copy() for i in range(nc)}

@@ -5,7 +5,11 @@ its adapter walks them (python/ddp.py:38-58, :125-151, :165-177).  Here the dyna
 analytic HIP models* (``Problem.setModel``); the surface keeps the call shapes the example loops and the walking-pattern
 scheduler use: ``createStateVariable / createInputVariable / createParameter``, ``Parameter.assign / getValues``,
 ``getState().getVars()``, ``getInput().getVars()``, ``getParameters()``, ``getDt()``, ``nodes``,
-``var_container.getVarList(offset=False)``.
+``var_container.getVarList(offset=False)``, and the function container the adapter reads its costs and constraints from:
+``createResidual / createConstraint / createIntermediateConstraint``, ``function_container.getCost() / getCnstr()``,
+``getNodes() / getLowerBounds() / getUpperBounds()`` (python/prb.py:166-204; python/ddp.py:38-48, :184-196, :218-224).
+Where the reference passes a CasADi expression, the builders here pass a ``Term``: the name of an analytic term of the
+registered model plus the gain it is scaled with.
 """
 from __future__ import annotations
 
@@ -121,6 +125,54 @@ class Aggregate:
         return (sum(v.getDim() for v in self._vars), 1)
 
 
+class Term:
+    """Stands where the symbolic expression of ``createResidual`` / ``createConstraint`` stands (prb.py:166-204): ``key`` names
+    an analytic term the registered HIP model implements, ``gain`` is the weight the reference puts under the square root in front
+    of it (``consts_key`` is the model constant that carries it; None: the term has no tunable gain)."""
+
+    def __init__(self, key: str, consts_key: str | None = None, gain: float | None = None, dim: int = 1):
+        self.key, self.consts_key, self.gain, self.dim = key, consts_key, gain, int(dim)
+
+    def __repr__(self):
+        return f"Term({self.key!r}, {self.consts_key}={self.gain})"
+
+
+class Function:
+    """A cost term or constraint of the problem (Horizon ``Function`` / ``Constraint`` as ddp.py:42-48, :184-196 use them)."""
+
+    def __init__(self, name: str, term: Term, nodes, lb=None, ub=None):
+        self._name, self.term = name, term
+        self._nodes = [int(n) for n in nodes]
+        self._lb = None if lb is None else np.broadcast_to(np.asarray(lb, dtype=float), (term.dim,)).copy()
+        self._ub = None if ub is None else np.broadcast_to(np.asarray(ub, dtype=float), (term.dim,)).copy()
+
+    def getName(self):
+        return self._name
+
+    def getNodes(self):
+        return list(self._nodes)
+
+    def getDim(self):
+        return self.term.dim
+
+    def getLowerBounds(self):
+        return self._lb.copy()
+
+    def getUpperBounds(self):
+        return self._ub.copy()
+
+
+class _FunContainer:
+    def __init__(self):
+        self._cost, self._cnstr = OrderedDict(), OrderedDict()
+
+    def getCost(self):
+        return self._cost
+
+    def getCnstr(self):
+        return self._cnstr
+
+
 class _VarContainer:
     def __init__(self, prb):
         self._prb = prb
@@ -141,6 +193,32 @@ class Problem:
         self.model = None
         self.model_consts = {}
         self.var_container = _VarContainer(self)
+        self.function_container = _FunContainer()
+
+    # ---- costs and constraints (prb.py:166-204).  Default nodes as Horizon's: every node ------------------------------------
+    def createResidual(self, name, term: Term, nodes=None):
+        if not isinstance(term, Term):
+            raise TypeError("createResidual needs a Term naming an analytic term of the registered model (no CasADi here)")
+        f = Function(name, term, range(self.nodes) if nodes is None else nodes)
+        self.function_container._cost[name] = f
+        return f
+
+    def createConstraint(self, name, term: Term, nodes=None, bounds=None):
+        if not isinstance(term, Term):
+            raise TypeError("createConstraint needs a Term naming an analytic term of the registered model (no CasADi here)")
+        b = bounds or {}
+        f = Function(name, term, range(self.nodes) if nodes is None else nodes, b.get("lb", 0.0), b.get("ub", 0.0))   # default: g = 0
+        self.function_container._cnstr[name] = f
+        return f
+
+    def createIntermediateConstraint(self, name, term: Term, nodes=None, bounds=None):
+        return self.createConstraint(name, term, range(self.nodes - 1) if nodes is None else nodes, bounds)
+
+    def removeCostFunction(self, name):
+        return self.function_container._cost.pop(name, None) is not None
+
+    def removeConstraint(self, name):
+        return self.function_container._cnstr.pop(name, None) is not None
 
     def createStateVariable(self, name, dim):
         if any(v.kind == "input" for v in self._vars):

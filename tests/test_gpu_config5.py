@@ -30,3 +30,30 @@ def test_srbd37_n60_multiple_shooting_matches_oracle():
         assert abs(eng.stats["gap"][b] - r.gap) <= 1e-9 * max(1.0, r.gap)
         assert np.max(np.abs(x[b] - r.xs)) <= 1e-7 and np.max(np.abs(u[b] - r.us)) <= 1e-7
         assert abs(eng.stats["cost"][b] - r.cost) <= 1e-9 * abs(r.cost)
+
+
+def test_srbd37_n60_solved_to_convergence_matches_the_c_oracle():
+    """configs[4] at its real size, to convergence: 12 seeds, every node's defect open at the start (perturbed x warm start),
+    example options (dsrbd_example.py:55-58) -- against the plain-C oracle (oracle/c, pinned to the numpy oracle for srbd37 in
+    tests/test_oracle_c.py): same iteration count, same status, trajectory l-inf and final cost."""
+    from oracle import cport
+    N, seeds = 60, np.arange(12) + 20
+    batch = workload.make_batch("srbd37", N, seeds)
+    rng = np.random.default_rng(9)
+    xs = batch["xs"] + 1e-3 * rng.standard_normal(batch["xs"].shape)
+    xs[:, 0] = batch["x0"]
+    opts = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
+    eng = DdpEngine("srbd37", N, len(seeds), opts=opts)
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(xs); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    st = eng.stats.copy()
+    xo, uo, so = cport.solve_batch(omodels.RobotConsts(**batch["consts"]), oddp.DdpOptions(**opts), batch["x0"], batch["params"], xs,
+                                   batch["us"], threads=4, model="srbd37")
+    print("srbd37 N=60: iterations GPU", st["iters"].tolist(), "oracle", so[:, 1].astype(int).tolist(),
+          "linf x", float(np.max(np.abs(x - xo))), "linf u", float(np.max(np.abs(u - uo))))
+    np.testing.assert_array_equal(st["iters"], so[:, 1].astype(int))
+    np.testing.assert_array_equal(st["status"], so[:, 6].astype(int))
+    np.testing.assert_array_equal(st["converged"], so[:, 2].astype(int))
+    assert st["converged"].all() and np.all(st["gap"] <= 1e-9) and st["iters"].min() >= 3
+    assert np.max(np.abs(x - xo)) <= 1e-6 and np.max(np.abs(u - uo)) <= 1e-6
+    np.testing.assert_allclose(st["cost"], so[:, 0], rtol=1e-9)
