@@ -141,6 +141,98 @@ static void corejac_n(const consts_t* c, const double* r, const double* o, const
         skew(nf, S); mm3(k->Mi, S, J->Wc[i]);
     }
 }
+/* Second derivatives of wdot = I_w(o)^-1 n(z), n = sum s (c_i - r) x f_i - w x I_w(o) w (oracle/models.py srbd_wdot_hess), from
+ * differentiating I_w wdot = n twice:  d_a d_b wdot = I_w^-1 (d_a d_b n - d_a d_b I_w wdot - d_a I_w d_b wdot - d_b I_w d_a wdot).
+ * Local variable order z = r(3) | o(4) | w(3) | c_0..(3 each) | f_0..(3 each), n = 10 + 6 nc.  S (n x n) += sum_m lam_m T[m]. */
+static void world_inertia_d2(const consts_t* c, const double* R, const double* dRp, const double* dRq, const double* d2R, double* d2M) {
+    if (c->inertia_mode == 0) {
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+            d2M[3 * i + j] = c->Is[3 * i + j] * (d2R[3 * i + j] * R[3 * j + i] + dRp[3 * i + j] * dRq[3 * j + i] + dRq[3 * i + j] * dRp[3 * j + i]
+                                                  + R[3 * i + j] * d2R[3 * j + i]);
+    } else {   /* d2R Is R^T + dRp Is dRq^T + dRq Is dRp^T + R Is d2R^T */
+        const double* L[4] = {d2R, dRp, dRq, R}; const double* Rr[4] = {R, dRq, dRp, d2R};
+        memset(d2M, 0, sizeof(double) * 9);
+        for (int t = 0; t < 4; ++t) {
+            double Rt[9], T[9], U[9];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt[3 * i + j] = Rr[t][3 * j + i];
+            mm3(c->Is, Rt, T); mm3(L[t], T, U);
+            for (int i = 0; i < 9; ++i) d2M[i] += U[i];
+        }
+    }
+}
+static void wdot_hess_contract(const consts_t* c, const double* r, const double* o, const double* w, int nc, const double* const* cs,
+                               const double* const* fs, const double* lam, double* S /* n x n, accumulated */) {
+    (void)cs; (void)r;
+    const int n = 10 + 6 * nc;
+    core_t k; corejac_t J;
+    core_n(c, r, o, w, nc, cs, fs, &k); corejac_n(c, r, o, w, nc, cs, fs, &k, &J);
+    double Jw[3][34];                                   /* d wdot / d z in the local order */
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) { Jw[a][b] = J.Wr[3 * a + b]; Jw[a][7 + b] = J.Ww[3 * a + b]; }
+        for (int b = 0; b < 4; ++b) Jw[a][3 + b] = J.Wo[4 * a + b];
+        for (int i = 0; i < nc; ++i) for (int b = 0; b < 3; ++b) { Jw[a][10 + 3 * i + b] = J.Wc[i][3 * a + b]; Jw[a][10 + 3 * nc + 3 * i + b] = J.Wf[i][3 * a + b]; }
+    }
+    double dR[4][9], dM[4][9], d2M[4][4][9];
+    for (int q = 0; q < 4; ++q) { quat_to_rot_d(o, q, dR[q]); world_inertia_d(c, k.R, dR[q], dM[q]); }
+    for (int p = 0; p < 4; ++p) for (int q = 0; q < 4; ++q) {
+        double eq[4] = {0, 0, 0, 0}, d2R[9]; eq[q] = 1.0;
+        quat_to_rot_d(eq, p, d2R);                       /* dR/dq_p is linear in the quaternion: its q-derivative = dR/dq_p at e_q */
+        world_inertia_d2(c, k.R, dR[p], dR[q], d2R, d2M[p][q]);
+    }
+    double y[3]; mv3(k.Mi, lam, y);                      /* I_w symmetric: lam^T I_w^-1 v = y . v */
+    const double s = c->lever;
+    for (int a = 0; a < n; ++a) for (int b = 0; b <= a; ++b) {
+        double v[3] = {0, 0, 0};
+        const int ao = a >= 3 && a < 7, bo = b >= 3 && b < 7, aw = a >= 7 && a < 10, bw = b >= 7 && b < 10;
+        const int af = a >= 10 + 3 * nc, bf = b >= 10 + 3 * nc, ac = a >= 10 && !af, bc = b >= 10 && !bf, br = b < 3;
+        if (af && (br || bc)) {                          /* bilinear torque: d2/(dc df) = s e_c x e_f, d2/(dr df) = -s e_r x e_f */
+            const int i = (a - 10 - 3 * nc) / 3, fa = (a - 10 - 3 * nc) % 3;
+            const int ok = br || (b - 10) / 3 == i, xa = br ? b : (b - 10) % 3;
+            if (ok) { double ex[3] = {0, 0, 0}, ef[3] = {0, 0, 0}, t[3]; ex[xa] = 1; ef[fa] = 1; cross(ex, ef, t);
+                      for (int m = 0; m < 3; ++m) v[m] = (br ? -s : s) * t[m]; }
+        } else if (aw && bw) {
+            double ea[3] = {0, 0, 0}, eb[3] = {0, 0, 0}, Ma[3], Mb[3], t1[3], t2[3]; ea[a - 7] = 1; eb[b - 7] = 1;
+            mv3(k.M, ea, Ma); mv3(k.M, eb, Mb); cross(ea, Mb, t1); cross(eb, Ma, t2);
+            for (int m = 0; m < 3; ++m) v[m] = -(t1[m] + t2[m]);
+        } else if (aw && bo) {
+            double ea[3] = {0, 0, 0}, t0[3], t1[3], t2[3], t3[3]; ea[a - 7] = 1;
+            mv3(dM[b - 3], w, t0); cross(ea, t0, t1); mv3(dM[b - 3], ea, t2); cross(w, t2, t3);
+            for (int m = 0; m < 3; ++m) v[m] = -(t1[m] + t3[m]);
+        } else if (ao && bo) {
+            double t0[3], t1[3]; mv3(d2M[a - 3][b - 3], w, t0); cross(w, t0, t1);
+            double t2[3]; mv3(d2M[a - 3][b - 3], k.wdot, t2);
+            for (int m = 0; m < 3; ++m) v[m] = -t1[m] - t2[m];
+        }
+        (void)ac;
+        if (ao) { double jb[3] = {Jw[0][b], Jw[1][b], Jw[2][b]}, t[3]; mv3(dM[a - 3], jb, t); for (int m = 0; m < 3; ++m) v[m] -= t[m]; }
+        if (bo) { double ja[3] = {Jw[0][a], Jw[1][a], Jw[2][a]}, t[3]; mv3(dM[b - 3], ja, t); for (int m = 0; m < 3; ++m) v[m] -= t[m]; }
+        const double val = y[0] * v[0] + y[1] * v[1] + y[2] * v[2];
+        S[a * n + b] += val; if (a != b) S[b * n + a] += val;
+    }
+}
+/* full second-order correction of a stage node (oracle/models.py _srbd_second_order_full): Q += theta * (sum_m lam_m d2 wdot_m +
+ * dt v'_o . d2 odot), lam = dt v'_w + 2 min_qddot_gain wdot; gl maps the local order to z columns (-1: not a variable) */
+static void srbd_second_order_full(const consts_t* c, const double* r, const double* o, const double* w, int nc, const double* const* cs,
+                                   const double* const* fs, const double* vp_o, const double* vp_w, const int* gl, int o0, int w0,
+                                   double theta, double* Q, int nz) {
+    const int n = 10 + 6 * nc;
+    core_t k; core_n(c, r, o, w, nc, cs, fs, &k);
+    double lam[3], S[34 * 34];
+    for (int m = 0; m < 3; ++m) lam[m] = c->dt * vp_w[m] + 2.0 * c->gq * k.wdot[m];
+    memset(S, 0, sizeof(double) * n * n);
+    wdot_hess_contract(c, r, o, w, nc, cs, fs, lam, S);
+    for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) if (gl[a] >= 0 && gl[b] >= 0) Q[gl[a] * nz + gl[b]] += theta * S[a * n + b];
+    for (int cc = 0; cc < 3; ++cc) {                     /* odot bilinear in (o, w): d(d odot/d o)/dw_c = Jo at w = e_c */
+        double e[3] = {0, 0, 0}; e[cc] = 1.0;
+        const double Jo[16] = {0, -0.5 * e[2], 0.5 * e[1], 0.5 * e[0], 0.5 * e[2], 0, -0.5 * e[0], 0.5 * e[1],
+                               -0.5 * e[1], 0.5 * e[0], 0, 0.5 * e[2], -0.5 * e[0], -0.5 * e[1], -0.5 * e[2], 0};
+        for (int b = 0; b < 4; ++b) {
+            double v = 0; for (int a = 0; a < 4; ++a) v += vp_o[a] * Jo[4 * a + b];
+            v *= theta * c->dt;
+            Q[(o0 + b) * nz + w0 + cc] += v; Q[(w0 + cc) * nz + o0 + b] += v;
+        }
+    }
+}
 /* quaternion kinematics odot = 1/2 [w;0] (x) o and its Jacobians (prb.py:107-108) */
 static void quat_step(const double* o, const double* w, double dt, double* on) {
     double wxo[3]; cross(w, o, wxo);
@@ -296,8 +388,14 @@ static int s13_residual(const consts_t* c, const double* x, const double* u, con
     return n;
 }
 /* exact bilinear-torque term: Qux[f_a][r_b] -= theta * s * skew(y)[a][b], y = I_w^-1 (dt v'_w)   */
-static void s13_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, double* Q) {
-    (void)u; (void)p;
+static void s13_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, int mode,
+                             double* Q) {
+    if (mode == 2) {
+        const double* cs[2] = {p + 11, p + 14}; const double* fs[2] = {u, u + 3};
+        const int gl[22] = {0, 1, 2, 3, 4, 5, 6, 10, 11, 12, -1, -1, -1, -1, -1, -1, 13, 14, 15, 16, 17, 18};
+        srbd_second_order_full(c, x, x + 3, x + 10, 2, cs, fs, vp + 3, vp + 10, gl, 3, 10, theta, Q, 19);
+        return;
+    }
     double R[9], M[9], Mi[9], lam[3], y[3], S[9];
     quat_to_rot(x + 3, R); world_inertia(c, R, M); inv3(M, Mi);
     for (int a = 0; a < 3; ++a) lam[a] = c->dt * vp[10 + a];
@@ -396,8 +494,19 @@ static int s37_residual(const consts_t* c, const double* x, const double* u, con
     }
     return n;
 }
-static void s37_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, double* Q) {
-    (void)u; (void)p;
+static void s37_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, int mode,
+                             double* Q) {
+    (void)p;
+    if (mode == 2) {
+        const double* cs[4] = {x + 7, x + 10, x + 13, x + 16}; const double* fs[4] = {u + 3, u + 9, u + 15, u + 21};
+        int gl[34];
+        for (int i = 0; i < 7; ++i) gl[i] = i;
+        for (int i = 0; i < 3; ++i) gl[7 + i] = 22 + i;
+        for (int i = 0; i < 12; ++i) gl[10 + i] = 7 + i;
+        for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) gl[22 + 3 * i + a] = 37 + 6 * i + 3 + a;
+        srbd_second_order_full(c, x, x + 3, x + 22, 4, cs, fs, vp + 3, vp + 22, gl, 3, 22, theta, Q, 61);
+        return;
+    }
     double R[9], M[9], Mi[9], lam[3], y[3], S[9];
     quat_to_rot(x + 3, R); world_inertia(c, R, M); inv3(M, Mi);
     for (int a = 0; a < 3; ++a) lam[a] = c->dt * vp[22 + a];
@@ -483,8 +592,9 @@ static int l30_residual(const consts_t* c, const double* x, const double* u, con
     }
     return n;
 }
-static void l30_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, double* Q) {
-    (void)c; (void)x; (void)u; (void)p; (void)vp; (void)theta; (void)Q;                      /* linear dynamics */
+static void l30_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, int mode,
+                             double* Q) {
+    (void)c; (void)x; (void)u; (void)p; (void)vp; (void)theta; (void)Q; (void)mode;                      /* linear dynamics */
 }
 #include "ddp_engine.inc"
 #undef NX

@@ -8,8 +8,9 @@ steps; tests compare the two iteration by iteration.
 
     defects   d_{k+1} = f(x_k,u_k) - x_{k+1}
     backward  v' = Vx+ + Vxx+ d ; Q* = l* + F^T (.) ; Quu += mu I ; k = -Quu^-1 Qu ; K = -Quu^-1 Qux
-              second_order: Qux += theta * (v'.f_ux restricted to the bilinear torque (c-r) x f); theta = 1 after a full
-              step (alpha == alpha_0) was accepted, else 0; a failed sweep or line search with theta = 1 is redone with 0
+              second_order 1: Qux += theta * (v'.f_ux restricted to the bilinear torque (c-r) x f); 2: Q += theta * (v'.f_zz +
+              exact - Gauss-Newton cost Hessian), all blocks; theta = 1 after a full step (alpha == alpha_0) was accepted,
+              else 0; a failed sweep or line search with theta = 1 is redone with 0
               Vx = Qx + Qux^T k ; Vxx = Qxx + Qux^T K (symmetrised)
               dV1 = sum k^T Qu ; dV2 = 1/2 sum k^T Quu k ; G1 = sum d^T Vx+ ; G2 = 1/2 sum d^T Vxx+ d
     forward   xh_0 = x0 ; uh_k = u_k + a k_k + K_k (xh_k - x_k) ; xh_{k+1} = f(xh_k,uh_k) - (1-a) d_{k+1}
@@ -36,7 +37,8 @@ class DdpOptions:
     cost_reduction_ths: float = 1e-6          # ddp.py:32-33 (engine default unpinned)
     mu0: float = 0.0                          # ddp.py:34-35 (engine default unpinned)
     initial_rollout: bool = False             # True: single shooting (x warm start ignored)
-    second_order: bool = True                 # exact bilinear-torque term v'.f_ux once full steps are accepted
+    second_order: int = 1                     # 1: exact bilinear-torque term v'.f_ux once full steps are accepted; 2: full second
+                                              # order (v'.f_zz and the exact cost Hessian, Model.second_order_full); 0: Gauss-Newton
     gap_tol: float = 1e-9
     mu_min: float = 1e-6
     mu_max: float = 1e12
@@ -78,7 +80,7 @@ def rollout_open_loop(model, x0, us, P):
     return xs
 
 
-def backward_pass(model, xs, us, P, d, mu, theta=0.0):
+def backward_pass(model, xs, us, P, d, mu, theta=0.0, mode=1):
     """-> ok, K [N,nu,nx], kff [N,nu], dV1, dV2, G1, G2, Vx0, Vxx0, qu_inf"""
     N = us.shape[0]
     nx, nu = model.nx, model.nu
@@ -97,9 +99,14 @@ def backward_pass(model, xs, us, P, d, mu, theta=0.0):
         Qu = lu + fu.T @ vp
         Qxx = lxx + fx.T @ Vxx @ fx
         Qux = lux + fu.T @ Vxx @ fx
-        if theta:
-            Qux = Qux + theta * model.second_order_ux(xs[k], us[k], P[k], vp)
         Quu = luu + fu.T @ Vxx @ fu + mu * np.eye(nu)
+        if theta and mode == 2:
+            S = theta * model.second_order_full(xs[k], us[k], P[k], k, vp)
+            Qxx = Qxx + S[:nx, :nx]
+            Qux = Qux + S[nx:, :nx]
+            Quu = Quu + S[nx:, nx:]
+        elif theta:
+            Qux = Qux + theta * model.second_order_ux(xs[k], us[k], P[k], vp)
         try:
             L = np.linalg.cholesky(Quu)
         except np.linalg.LinAlgError:
@@ -156,7 +163,7 @@ def solve(model, x0, P, xs_ws, us_ws, opt: DdpOptions | None = None) -> DdpResul
     while iters < opt.max_iters:
         # ---- backward sweep (regularisation bump on a non-PD Quu: this is what mu0 is for, ddp.py:34-35)
         while True:
-            ok, K, kff, dV1, dV2, G1, G2, Vx0, Vxx0, qu_inf = backward_pass(model, xs, us, P, d, mu, theta)
+            ok, K, kff, dV1, dV2, G1, G2, Vx0, Vxx0, qu_inf = backward_pass(model, xs, us, P, d, mu, theta, int(opt.second_order))
             if ok:
                 break
             if theta:

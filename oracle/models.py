@@ -129,6 +129,80 @@ def world_inertia(cst: RobotConsts, o):
     return M, dM
 
 
+def world_inertia_hess(cst: RobotConsts, o):
+    """d2 I_w / do_p do_q (4 x 4 list of 3x3).  R is quadratic in the quaternion, so dR/dq is linear and its derivative constant."""
+    R = quat_to_rot(o)
+    dR = quat_to_rot_jac(o)
+    E = np.eye(4)
+    d2R = [[quat_to_rot_jac(E[q])[p] for q in range(4)] for p in range(4)]        # d(dR/dq_p)/dq_q = dR/dq_p evaluated at e_q
+    Is = np.asarray(cst.I) / cst.force_scaling
+    if cst.inertia_mode == 0:
+        return [[Is * (d2R[p][q] * R.T + dR[p] * dR[q].T + dR[q] * dR[p].T + R * d2R[p][q].T) for q in range(4)] for p in range(4)]
+    return [[d2R[p][q] @ Is @ R.T + dR[p] @ Is @ dR[q].T + dR[q] @ Is @ dR[p].T + R @ Is @ d2R[p][q].T for q in range(4)]
+            for p in range(4)]
+
+
+def srbd_wdot_hess(cst: RobotConsts, r, o, w, cs, fs):
+    """Second derivatives of wdot = I_w(o)^-1 (sum s (c_i - r) x f_i - w x I_w(o) w)  (prb.py:99; north_star "analytic second
+    derivatives").  -> T [3, n, n] over the local variable order z = r(3) | o(4) | w(3) | c_0..(3 each) | f_0..(3 each), from
+    differentiating I_w wdot = n twice:  d_a d_b wdot = I_w^-1 (d_a d_b n - d_a d_b I_w wdot - d_a I_w d_b wdot - d_b I_w d_a wdot)."""
+    nc = len(cs)
+    n = 10 + 6 * nc
+    iO, iW = 3, 7
+    iC = lambda i: 10 + 3 * i
+    iF = lambda i: 10 + 3 * nc + 3 * i
+    M, dM = world_inertia(cst, o)
+    d2M = world_inertia_hess(cst, o)
+    Minv = np.linalg.inv(M)
+    J = srbd_acc_jac(cst, r, o, w, cs, fs)
+    Jw = np.zeros((3, n))
+    Jw[:, 0:3], Jw[:, iO:iO + 4], Jw[:, iW:iW + 3] = J["wdot_r"], J["wdot_o"], J["wdot_w"]
+    for i in range(nc):
+        Jw[:, iC(i):iC(i) + 3] = J["wdot_c"][i]
+        Jw[:, iF(i):iF(i) + 3] = J["wdot_f"][i]
+    _, wdot = srbd_acc(cst, r, o, w, cs, fs)
+    E = np.eye(3)
+    s = cst.lever_sign
+    d2n = np.zeros((n, n, 3))
+    for i in range(nc):
+        for a in range(3):
+            for b in range(3):
+                v = s * np.cross(E[a], E[b])                       # d2 / dc_a df_b of s (c - r) x f ; d2 / dr_a df_b is its negative
+                d2n[iC(i) + a, iF(i) + b] += v; d2n[iF(i) + b, iC(i) + a] += v
+                d2n[a, iF(i) + b] -= v; d2n[iF(i) + b, a] -= v
+    for a in range(3):
+        for b in range(3):
+            d2n[iW + a, iW + b] = -(np.cross(E[a], M @ E[b]) + np.cross(E[b], M @ E[a]))
+        for q in range(4):
+            v = -(np.cross(E[a], dM[q] @ w) + np.cross(w, dM[q] @ E[a]))
+            d2n[iW + a, iO + q] = v; d2n[iO + q, iW + a] = v
+    for p_ in range(4):
+        for q in range(4):
+            d2n[iO + p_, iO + q] = -np.cross(w, d2M[p_][q] @ w)
+    T = np.zeros((3, n, n))
+    for a in range(n):
+        for b in range(n):
+            v = d2n[a, b].copy()
+            if iO <= a < iO + 4 and iO <= b < iO + 4:
+                v -= d2M[a - iO][b - iO] @ wdot
+            if iO <= a < iO + 4:
+                v -= dM[a - iO] @ Jw[:, b]
+            if iO <= b < iO + 4:
+                v -= dM[b - iO] @ Jw[:, a]
+            T[:, a, b] = Minv @ v
+    return T, wdot
+
+
+def quat_rate_hess_contract(vo):
+    """sum_a vo_a d2 odot_a / do_b dw_c  [4 x 3]: odot is bilinear in (o, w), so d(d odot/d o)/dw_c = Jo evaluated at w = e_c."""
+    S = np.zeros((4, 3))
+    z4 = np.zeros(4)
+    for c in range(3):
+        Jo, _ = quat_rate_jac(z4, np.eye(3)[c])
+        S[:, c] = vo @ Jo
+    return S
+
+
 def srbd_acc(cst: RobotConsts, r, o, w, cs, fs):
     """rddot, wdot for contact points ``cs`` and (scaled) forces ``fs`` (prb.py:92-99, App. A.3)."""
     ms = cst.m / cst.force_scaling
@@ -221,6 +295,13 @@ class Model:
         the bilinear torque (c - r) x f of prb.py:99 (constant tensor).  Zero for linear models."""
         return np.zeros((self.nu, self.nx))
 
+    def second_order_full(self, x, u, p, k, vp):
+        """Full second-order correction of a stage node, [nz x nz] over z = [x u] (second_order = 2, "full DDP"):
+        sum_i vp_i d2 f_i / dz dz   (the dynamics tensor contracted with v' = Vx+ + Vxx+ d)
+        + (exact Hessian of L_k - its Gauss-Newton part 2 J^T J) = sum_j 2 res_j d2 res_j / dz dz.
+        Zero for linear-quadratic models."""
+        return np.zeros((self.nx + self.nu, self.nx + self.nu))
+
     def initial_state(self):
         raise NotImplementedError
 
@@ -307,6 +388,11 @@ class SRBD13(Model):
             S[3 * i:3 * i + 3, self.R_] = -self.cst.lever_sign * skew(y)      # d2 (y.((c-r) x f)) / df dr
         return S
 
+    def second_order_full(self, x, u, p, k, vp):
+        r, o, rd, w, cs, fs = self._split(x, u, p)
+        return _srbd_second_order_full(self.cst, 19, r, o, w, cs, fs, vp[self.O_], vp[self.W_], self.O_.start, self.W_.start,
+                                       None, [13, 16])
+
     def initial_state(self):
         return np.concatenate([self.cst.com, [0, 0, 0, 1.0], np.zeros(6)])        # prb.py:224-240 reduced
 
@@ -328,6 +414,33 @@ class SRBD13(Model):
         P[:, self.P_SW[0]] = 1.0
         P[:, self.P_SW[1]] = 1.0                                                   # prb.py:163
         return P
+
+
+def _srbd_second_order_full(cst, nz, r, o, w, cs, fs, vp_o, vp_w, o0, w0, c_idx, f_idx):
+    """Shared by srbd13 / srbd37.  The only non-linear pieces are wdot (dynamics rows w, and the wdot rows of the min_qddot
+    residual, prb.py:200) and the bilinear quaternion kinematics (prb.py:107-108):
+        S = sum_m lam_m d2 wdot_m  +  dt * (v'_o . d2 odot),   lam = dt v'_w + 2 min_qddot_gain wdot.
+    c_idx: state columns of the contact points (None: contacts are parameters), f_idx: z columns of the forces."""
+    nc = len(cs)
+    T, wdot = srbd_wdot_hess(cst, r, o, w, cs, fs)
+    lam = cst.dt * vp_w + 2.0 * cst.min_qddot_gain * wdot
+    Sl = np.tensordot(lam, T, axes=(0, 0))
+    n = 10 + 6 * nc
+    gl = np.full(n, -1)                                            # local -> global z index
+    gl[0:3] = [0, 1, 2]
+    gl[3:7] = o0 + np.arange(4)
+    gl[7:10] = w0 + np.arange(3)
+    for i in range(nc):
+        if c_idx is not None:
+            gl[10 + 3 * i:13 + 3 * i] = c_idx[i] + np.arange(3)
+        gl[10 + 3 * nc + 3 * i:13 + 3 * nc + 3 * i] = f_idx[i] + np.arange(3)
+    S = np.zeros((nz, nz))
+    keep = gl >= 0
+    S[np.ix_(gl[keep], gl[keep])] = Sl[np.ix_(keep, keep)]
+    Q = cst.dt * quat_rate_hess_contract(vp_o)
+    S[o0:o0 + 4, w0:w0 + 3] += Q
+    S[w0:w0 + 3, o0:o0 + 4] += Q.T
+    return S
 
 
 def _srbd_state_rows(rows, c, r, o, rd, w, rdot_ref, w_ref, otg, oref, R_, O_, RD_, W_):
@@ -502,6 +615,11 @@ class SRBD37(Model):
             S[6 * i + 3:6 * i + 6, self.R_] = -self.cst.lever_sign * skew(y)
             S[6 * i + 3:6 * i + 6, self.C_IDX[i]:self.C_IDX[i] + 3] = self.cst.lever_sign * skew(y)
         return S
+
+    def second_order_full(self, x, u, p, k, vp):
+        r, o, rd, w, cs, cds, cdd, fs = self._split(x, u)
+        return _srbd_second_order_full(self.cst, 61, r, o, w, cs, fs, vp[self.O_], vp[self.W_], self.O_.start, self.W_.start,
+                                       self.C_IDX, [37 + 6 * i + 3 for i in range(4)])
 
     def initial_state(self):
         feet = np.asarray(self.cst.feet)

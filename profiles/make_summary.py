@@ -3,6 +3,7 @@ usage: python profiles/make_summary.py r01 <trace_dir> <pmc_fetch_dir> <pmc_writ
 import collections, csv, glob, json, os, shutil, sys
 
 rnd, trace, pf, pw, psq, blog = sys.argv[1:7]
+steps = int(sys.argv[7]) if len(sys.argv) > 7 else 20
 out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), rnd)
 os.makedirs(out_dir, exist_ok=True)
 one = lambda d, pat: sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))[0]
@@ -27,6 +28,7 @@ out["SQ"] = {k: sum(v) / len(v) for k, v in sq.items()}
 f, w = out["FETCH_SIZE"]["mean"], out["WRITE_SIZE"]["mean"]
 out["traffic_bytes_per_launch"] = (2 * f + w) * 1024
 out["traffic_bytes_per_launch_uncorrected"] = (f + w) * 1024
+out["batches_per_launch"] = steps            # every launch of the profiled command solves `steps` batches of 1024 instances
 # rocprofv3 per-dispatch durations of the traced run, split like bench.py splits them (warm-up launches are not in its HIP-event mean)
 tr = sorted(glob.glob(os.path.join(trace, "**", "*kernel_trace.csv"), recursive=True))
 if tr:
@@ -34,14 +36,15 @@ if tr:
     dur = [(e - s0) / 1e6 for s0, e in ks]
     tl0 = os.path.join(os.path.dirname(blog), "trace.log")
     tj = json.loads([l for l in open(tl0) if l.startswith("{")][-1]) if os.path.exists(tl0) else None
-    nw = tj["warmup"] if tj else 0
+    nw = len(dur) - (tj["config"]["launches_timed"] if tj else len(dur))      # priming launches come first
     out["traced_run"] = {"launches": len(dur), "warmup_launches": nw, "rocprof_mean_ms_all": sum(dur) / len(dur),
                          "rocprof_mean_ms_timed": sum(dur[nw:]) / max(1, len(dur) - nw),
                          "hip_event_mean_ms_timed": tj["roofline"]["kernel_ms"] if tj else None}
-out["note"] = ("rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_* each in its own run) of `python3 bench.py --steps 32 --warmup 16 "
-               "--no-cpu-baseline --no-sequential` (16 batches in flight, the bench default); FETCH/WRITE_SIZE in KiB; gfx950 correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE "
-               "doubled (calibrated for 16 B/lane streams; this kernel reads 8 B/lane, so the uncorrected figure is also given). "
-               "Kernel = solve_kernel_w2<SrbdModel<2,false>>, B=1024, N=30; means over all dispatches of the run.")
+out["note"] = (f"rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_* each in its own run) of `python3 bench.py --steps {steps} --warmup 5 "
+               "--no-cpu-baseline --no-extras` (one priming launch + one timed launch, each a work queue of steps x 1024 instances on the "
+               "resident wavefronts); FETCH/WRITE_SIZE in KiB; gfx950 correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE doubled "
+               "(calibrated for 16 B/lane streams; this kernel reads 8 B/lane, so the uncorrected figure is also given). "
+               "Kernel = solve_kernel_w2<SrbdModel<2,false>>, N=30; means over the dispatches of the run.")
 json.dump(out, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1)
 line = [l for l in open(blog) if l.startswith("{")][-1]
 d = json.loads(line)
@@ -52,6 +55,6 @@ if os.path.exists(tl):                                          # the bench line
     tline = [l for l in open(tl) if l.startswith("{")][-1]      # must agree with kernel_stats_bench.csv
     open(os.path.join(out_dir, "bench_line_traced_run.json"), "w").write(tline)
 print({k: d.get(k) for k in ("value", "ms_per_step", "mean_iters", "mean_rollouts", "converged_frac", "iterations_per_s",
-                              "pcie_inclusive_solves_per_s", "one_batch_in_flight_solves_per_s")})
+                              "pcie_inclusive_solves_per_s", "one_batch_in_flight_solves_per_s", "index_order_solves_per_s")})
 print(d["roofline"]); print(d.get("cpu_baseline")); print(d.get("ms_per_mpc_tick")); print(out["SQ"]); print(out["kernel"])
 print(open(os.path.join(out_dir, "kernel_stats_bench.csv")).read())

@@ -27,11 +27,11 @@ struct Dims {
     size_t lds;
 };
 
-// bar: the friction-cone barrier build of the SRBD models (longer derivative record)
-bool model_dims(int id, Dims& d, bool bar = false) {
+// bar: the friction-cone barrier build of the SRBD models, so2: the full second-order build (longer derivative records)
+bool model_dims(int id, Dims& d, bool bar = false, bool so2 = false) {
     switch (id) {
-        case SDDP_MODEL_SRBD13: d = {Srbd13::NX, Srbd13::NU, Srbd13::NP, bar ? Srbd13B::NREC : Srbd13::NREC, Lds<Srbd13>::BYTES}; return true;
-        case SDDP_MODEL_SRBD37: d = {Srbd37::NX, Srbd37::NU, Srbd37::NP, bar ? Srbd37B::NREC : Srbd37::NREC, Lds<Srbd37>::BYTES}; return true;
+        case SDDP_MODEL_SRBD13: d = {Srbd13::NX, Srbd13::NU, Srbd13::NP, so2 ? Srbd13S::NREC : (bar ? Srbd13B::NREC : Srbd13::NREC), Lds<Srbd13>::BYTES}; return true;
+        case SDDP_MODEL_SRBD37: d = {Srbd37::NX, Srbd37::NU, Srbd37::NP, so2 ? Srbd37S::NREC : (bar ? Srbd37B::NREC : Srbd37::NREC), Lds<Srbd37>::BYTES}; return true;
         case SDDP_MODEL_LIP30: d = {Lip30::NX, Lip30::NU, Lip30::NP, Lip30::NREC, Lds<Lip30>::BYTES}; return true;
         default: return false;
     }
@@ -60,6 +60,7 @@ struct sddp_handle {
     std::string err;
     bool have_x0 = false, have_xws = false, have_uws = false, have_params = false;
     bool bar = false;               // friction-cone barrier build (consts.friction_barrier_weight > 0)
+    bool so2 = false;               // full second-order build (opts.second_order == 2 at sddp_create)
     double* tick_in = nullptr;      // [B][np + nx] staging of sddp_advance
     double* step_buf = nullptr;     // [B][2 nx + nu + np] operands and result of sddp_model_step
     char* tick_pin = nullptr;       // two pinned images of tick_in (small batches)
@@ -248,8 +249,8 @@ int launch_model_step(sddp_handle* h, int k, const double* dx, const double* du,
 
 #define DISPATCH(h, fn, ...)                                                 \
     switch ((h)->model_id) {                                                 \
-        case SDDP_MODEL_SRBD13: rc = (h)->bar ? fn<Srbd13B>(__VA_ARGS__) : fn<Srbd13>(__VA_ARGS__); break; \
-        case SDDP_MODEL_SRBD37: rc = (h)->bar ? fn<Srbd37B>(__VA_ARGS__) : fn<Srbd37>(__VA_ARGS__); break; \
+        case SDDP_MODEL_SRBD13: rc = (h)->so2 ? fn<Srbd13S>(__VA_ARGS__) : ((h)->bar ? fn<Srbd13B>(__VA_ARGS__) : fn<Srbd13>(__VA_ARGS__)); break; \
+        case SDDP_MODEL_SRBD37: rc = (h)->so2 ? fn<Srbd37S>(__VA_ARGS__) : ((h)->bar ? fn<Srbd37B>(__VA_ARGS__) : fn<Srbd37>(__VA_ARGS__)); break; \
         case SDDP_MODEL_LIP30: rc = fn<Lip30>(__VA_ARGS__); break;            \
         default: rc = SDDP_ERR_MODEL;                                         \
     }
@@ -278,6 +279,7 @@ int validate_options(sddp_handle* h, const sddp_options& o) {
         if (!std::isfinite(v)) return fail(h, SDDP_ERR_ARG, "non-finite value in sddp_options");
     if (!(o.mu_max > o.mu_min)) return fail(h, SDDP_ERR_ARG, "mu_max must be > mu_min");
     if (o.queue_order != 0 && o.queue_order != 1) return fail(h, SDDP_ERR_ARG, "queue_order must be 0 or 1");
+    if (o.second_order < 0 || o.second_order > 2) return fail(h, SDDP_ERR_ARG, "second_order must be 0, 1 or 2");
     return SDDP_OK;
 }
 
@@ -342,7 +344,9 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     *out = nullptr;
     Dims d;
     const bool bar = consts && consts->friction_barrier_weight > 0.0 && model_id != SDDP_MODEL_LIP30;
-    if (!model_dims(model_id, d, bar)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
+    const bool so2 = opts && opts->second_order == 2 && model_id != SDDP_MODEL_LIP30;     // (the LIP model is linear-quadratic: nothing to add)
+    if (bar && so2) return fail(nullptr, SDDP_ERR_ARG, "second_order = 2 is not available together with the friction-cone barrier");
+    if (!model_dims(model_id, d, bar, so2)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
     if (N < 1 || batch < 1) return fail(nullptr, SDDP_ERR_ARG, "N and batch must be >= 1");
     if (consts && (consts->friction_barrier_weight < 0.0 || (bar && !(consts->friction_cone_coefficient > 0.0))))
         return fail(nullptr, SDDP_ERR_ARG, "friction_barrier_weight must be >= 0 and friction_cone_coefficient > 0");
@@ -351,7 +355,7 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
         return fail(nullptr, SDDP_ERR_HIP, "no HIP device visible: the SDDP engine has no CPU fallback");
     sddp_handle* h = new (std::nothrow) sddp_handle();
     if (!h) return fail(nullptr, SDDP_ERR_NOMEM, "out of host memory");
-    h->model_id = model_id; h->N = N; h->B = batch; h->d = d; h->bar = bar;
+    h->model_id = model_id; h->N = N; h->B = batch; h->d = d; h->bar = bar; h->so2 = so2;
     if (opts) h->opts = *opts; else sddp_default_options(&h->opts);
     if (consts) h->consts = *consts; else sddp_default_consts(&h->consts);
     int rc = validate_options(h, h->opts);
@@ -430,6 +434,8 @@ int sddp_set_options(sddp_handle* h, const sddp_options* opts) {
     if (!h || !opts) return SDDP_ERR_ARG;
     int rc = validate_options(h, *opts);
     if (rc != SDDP_OK) return rc;
+    if ((opts->second_order == 2) != (h->opts.second_order == 2) && h->model_id != SDDP_MODEL_LIP30)
+        return fail(h, SDDP_ERR_ARG, "second_order = 2 selects another kernel build and record size: choose it at sddp_create");
     h->opts = *opts;
     return SDDP_OK;
 }

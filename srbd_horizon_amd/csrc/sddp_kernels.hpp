@@ -24,7 +24,10 @@
 namespace sddp {
 
 constexpr int kWave = 64;
-constexpr int kSlots = 8;   // line-search candidates whose trajectories are kept per pass (one-wave kernel)
+#ifndef SDDP_KSLOTS
+#define SDDP_KSLOTS 6
+#endif
+constexpr int kSlots = SDDP_KSLOTS;   // line-search candidates whose trajectories are kept per pass (one-wave kernel)
 constexpr int kScal = 24;  // doubles per instance in the scratch `scal` record (test kernels / diagnostic stamps)
 
 // Diagnostic build only (-DSDDP_STAMPS): per-phase shader-cycle sums, written to `scal`; never in the shipped library.
@@ -879,17 +882,18 @@ __device__ __forceinline__ void solve_instance(const SolveArgs& A, double* s, co
 template <class M>
 __device__ __forceinline__ void solve_queue(const SolveArgs& A, double* s) {
     const int slot = blockIdx.x;
-    if (!A.qhead) {
-        if (slot < A.count) solve_instance<M>(A, s, A.first + slot, slot);
-        return;
-    }
-    while (true) {
-        int i = 0;
+    const bool queued = A.qhead != nullptr;
+    int i = slot;                                      // no queue: workgroup w solves instance first + w
+    if (queued) {
         if (threadIdx.x == 0) i = atomicAdd(A.qhead, 1);
         i = __builtin_amdgcn_readfirstlane(i);
-        if (i >= A.count) break;                       // every wavefront reaches this: the head only grows
-        const int b = A.order ? A.order[i] : A.first + i;
-        solve_instance<M>(A, s, b, slot);
+    }
+    while (i < A.count) {                              // every wavefront reaches the exit: the head only grows
+        const int b = (queued && A.order) ? A.order[i] : A.first + i;
+        solve_instance<M>(A, s, b, slot);              // one call site: the body is compiled once
+        if (!queued) break;
+        if (threadIdx.x == 0) i = atomicAdd(A.qhead, 1);
+        i = __builtin_amdgcn_readfirstlane(i);
     }
 }
 

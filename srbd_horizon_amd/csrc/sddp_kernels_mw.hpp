@@ -805,18 +805,17 @@ __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double s[];
     __shared__ int q_pos;
     const int slot = blockIdx.x;
-    if (!A.qhead) {
-        if (slot < A.count) solve_instance_mw<M>(A, s, A.first + slot, slot);
-        return;
-    }
-    while (true) {
+    const bool queued = A.qhead != nullptr;
+    if (queued && threadIdx.x == 0) q_pos = atomicAdd(A.qhead, 1);
+    __syncthreads();
+    int i = queued ? q_pos : slot;
+    while (i < A.count) {
+        const int b = (queued && A.order) ? A.order[i] : A.first + i;
+        solve_instance_mw<M>(A, s, b, slot);           // ends with a barrier: q_pos may be rewritten
+        if (!queued) break;
         if (threadIdx.x == 0) q_pos = atomicAdd(A.qhead, 1);
         __syncthreads();
-        const int i = q_pos;
-        __syncthreads();
-        if (i >= A.count) break;
-        const int b = A.order ? A.order[i] : A.first + i;
-        solve_instance_mw<M>(A, s, b, slot);
+        i = q_pos;
     }
 }
 

@@ -184,15 +184,49 @@ __device__ __forceinline__ void world_inertia_d(const DevConsts& c, const double
     }
 }
 
+// runtime-index dR/dq_a (the full second-order builds loop over quaternion components)
+__device__ inline void quat_to_rot_dyn(const double* q, int a, double* D) {
+    switch (a) {
+        case 0: quat_to_rot_d<0>(q, D); break;
+        case 1: quat_to_rot_d<1>(q, D); break;
+        case 2: quat_to_rot_d<2>(q, D); break;
+        default: quat_to_rot_d<3>(q, D); break;
+    }
+}
+// d2 I_w / dq_p dq_q from R, dR/dq_p, dR/dq_q and the (constant) d2R/dq_p dq_q
+__device__ inline void world_inertia_d2(const DevConsts& c, const double* R, const double* dRp, const double* dRq, const double* d2R,
+                                        double* d2M) {
+    if (c.inertia_mode == 0) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                d2M[3 * i + j] = c.Is[3 * i + j] * (d2R[3 * i + j] * R[3 * j + i] + dRp[3 * i + j] * dRq[3 * j + i] +
+                                                    dRq[3 * i + j] * dRp[3 * j + i] + R[3 * i + j] * d2R[3 * j + i]);
+    } else {   // d2R Is R^T + dRp Is dRq^T + dRq Is dRp^T + R Is d2R^T
+        const double* L[4] = {d2R, dRp, dRq, R};
+        const double* Rr[4] = {R, dRq, dRp, d2R};
+        for (int i = 0; i < 9; ++i) d2M[i] = 0.0;
+        for (int t = 0; t < 4; ++t) {
+            double T[9], U[9];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    T[3 * i + j] = c.Is[3 * i] * Rr[t][3 * j] + c.Is[3 * i + 1] * Rr[t][3 * j + 1] + c.Is[3 * i + 2] * Rr[t][3 * j + 2];
+            matmul3(L[t], T, U);
+            for (int i = 0; i < 9; ++i) d2M[i] += U[i];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // SRBD family.  CS=false, NC=2: srbd13 (metric model, contacts are parameters);  CS=true, NC=4: srbd37
 // (reference problem, contacts are states -- prb.py:32-68).
 // ---------------------------------------------------------------------------------------------------------
-template <int NC_, bool CS_, bool BAR_ = false>
+template <int NC_, bool CS_, bool BAR_ = false, bool SO2_ = false>
 struct SrbdModel {
     static constexpr int NC = NC_;
     static constexpr bool CS = CS_;
     static constexpr bool BAR = BAR_;      // friction-cone exponential barrier on the contact forces (sddp.h), separate builds
+    static constexpr bool SO2 = SO2_;      // full second-order builds (sddp_options.second_order = 2): the record also carries the
+                                           // second derivatives of wdot, add_second_order adds the whole term
     static constexpr int NX = CS ? 13 + 6 * NC : 13;
     static constexpr int NU = CS ? 6 * NC : 3 * NC;
     static constexpr int NZ = NX + NU;
@@ -205,7 +239,10 @@ struct SrbdModel {
     // derivative record of one knot
     static constexpr int REC_A = 0, REC_JO = 3 * NA, REC_JW = REC_JO + 16, REC_MI = REC_JW + 12, REC_G = REC_MI + 9,
                          REC_B = REC_G + NZ,                       // BAR: barrier Hessian per contact: hxx hyy hzz hxz hyz
-                         NREC = REC_B + (BAR ? 5 * NC : 0);
+                         REC_WD = REC_B + (BAR ? 5 * NC : 0),      // SO2: wdot (3), then T[e][m] = d2 wdot_m / dz_a dz_b for the
+                         REC_T = REC_WD + 3,                       //      lower-triangle pairs e = a (a + 1) / 2 + b of the NA compact columns
+                         NTRI = NA * (NA + 1) / 2,
+                         NREC = SO2 ? REC_T + 3 * NTRI : REC_WD;
 
     __device__ __forceinline__ static int uf(int i) { return CS ? 6 * i + 3 : 3 * i; }  // prb.py:66-68 interleaved
     // parameter layouts: srbd37 = creation order; srbd13 = App. A.7
@@ -515,6 +552,7 @@ struct SrbdModel {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) rec[REC_JW + i] = Jw[i];
             }
+            if (SO2) wdot_hess(c, o, w, f, q, A, rec);
             // gradient of the input residuals: min_qddot rows [rddot; wdot; cddot], min_f, f_active, penalties
             const double s = 2 * c.gq;
 #pragma unroll
@@ -558,6 +596,76 @@ struct SrbdModel {
         }
 #pragma unroll
         for (int i = 0; i < NZ; ++i) rec[REC_G + i] = g[i];
+    }
+
+    // Second derivatives of wdot = I_w(o)^-1 n(z), n = sum s (c_i - r) x f_i - w x I_w(o) w, over the NA compact columns
+    // r | o | w | [c] | f, from differentiating I_w wdot = n twice (oracle/models.py srbd_wdot_hess):
+    //   d_a d_b wdot = I_w^-1 (d_a d_b n - d_a d_b I_w wdot - d_a I_w d_b wdot - d_b I_w d_a wdot).
+    // Runs once per knot and iteration in the lane-per-knot derivative phase; plain loops (private arrays), not unrolled.
+    __device__ __noinline__ static void wdot_hess(const DevConsts& c, const double* o, const double* w, const double (*f)[3], const Core& q,
+                                                  const double (*A)[NA], double* rec) {
+        double dM[4][9], d2M[4][4][9];
+        {
+            double dR[4][9];
+            for (int a = 0; a < 4; ++a) { quat_to_rot_dyn(o, a, dR[a]); world_inertia_d(c, q.R, dR[a], dM[a]); }
+            for (int p = 0; p < 4; ++p)
+                for (int b = 0; b <= p; ++b) {
+                    double eq[4] = {0, 0, 0, 0}, d2R[9];
+                    eq[b] = 1.0;
+                    quat_to_rot_dyn(eq, p, d2R);            // dR/dq_p is linear in q: its q_b derivative is dR/dq_p at e_b
+                    world_inertia_d2(c, q.R, dR[p], dR[b], d2R, d2M[p][b]);
+                    for (int i = 0; i < 9; ++i) d2M[b][p][i] = d2M[p][b][i];
+                }
+        }
+        (void)f;
+        for (int m = 0; m < 3; ++m) rec[REC_WD + m] = q.wdot[m];
+        const double s = c.lever;
+        int e = 0;
+        for (int a = 0; a < NA; ++a)
+            for (int b = 0; b <= a; ++b, ++e) {
+                double v[3] = {0, 0, 0};
+                const bool ao = a >= 3 && a < 7, bo = b >= 3 && b < 7, aw = a >= 7 && a < 10, bw = b >= 7 && b < 10;
+                const bool af = a >= AF, br = b < 3, bc = CS && b >= AC && b < AF;
+                if (af && (br || bc)) {     // bilinear torque: d2/(dc df) = s e_c x e_f, d2/(dr df) = -s e_r x e_f
+                    const int i = (a - AF) / 3, fa = (a - AF) % 3;
+                    const bool hit = br || (b - AC) / 3 == i;
+                    const int xa = br ? b : (b - AC) % 3;
+                    if (hit && xa != fa) {
+                        const int third = 3 - xa - fa;
+                        const double sg = ((fa - xa + 3) % 3 == 1) ? 1.0 : -1.0;       // (e_x x e_f)[third]
+                        v[third] = (br ? -s : s) * sg;
+                    }
+                } else if (aw && bw) {
+                    double ea[3] = {0, 0, 0}, eb[3] = {0, 0, 0}, Ma[3], Mb[3], t1[3], t2[3];
+                    ea[a - 7] = 1.0; eb[b - 7] = 1.0;
+                    matvec3(q.M, ea, Ma); matvec3(q.M, eb, Mb); cross3(ea, Mb, t1); cross3(eb, Ma, t2);
+                    for (int m = 0; m < 3; ++m) v[m] = -(t1[m] + t2[m]);
+                } else if (aw && bo) {
+                    double ea[3] = {0, 0, 0}, t0[3], t1[3], t2[3], t3[3];
+                    ea[a - 7] = 1.0;
+                    matvec3(dM[b - 3], w, t0); cross3(ea, t0, t1); matvec3(dM[b - 3], ea, t2); cross3(w, t2, t3);
+                    for (int m = 0; m < 3; ++m) v[m] = -(t1[m] + t3[m]);
+                } else if (ao && bo) {
+                    double t0[3], t1[3], t2[3];
+                    matvec3(d2M[a - 3][b - 3], w, t0); cross3(w, t0, t1); matvec3(d2M[a - 3][b - 3], q.wdot, t2);
+                    for (int m = 0; m < 3; ++m) v[m] = -t1[m] - t2[m];
+                }
+                if (ao) {
+                    const double jb[3] = {A[0][b], A[1][b], A[2][b]};
+                    double t[3];
+                    matvec3(dM[a - 3], jb, t);
+                    for (int m = 0; m < 3; ++m) v[m] -= t[m];
+                }
+                if (bo) {
+                    const double ja[3] = {A[0][a], A[1][a], A[2][a]};
+                    double t[3];
+                    matvec3(dM[b - 3], ja, t);
+                    for (int m = 0; m < 3; ++m) v[m] -= t[m];
+                }
+                double t[3];
+                matvec3(q.Mi, v, t);
+                for (int m = 0; m < 3; ++m) rec[REC_T + 3 * e + m] = t[m];
+            }
     }
 
     template <int QA>
@@ -832,6 +940,38 @@ struct SrbdModel {
     static constexpr int NSO = 9 * NC * (CS ? 2 : 1);
     __device__ __forceinline__ static void add_second_order(const DevConsts& c, const double* rec, const double* vp, double* Q,
                                                             int NZP, double theta, int lane, int nlanes) {
+        if (SO2) {
+            // full term (second_order = 2): Q += theta * (sum_m lam_m d2 wdot_m + dt v'_o . d2 odot), lam = dt v'_w + 2 gq wdot: the
+            // dynamics tensor contracted with v' plus the exact-minus-Gauss-Newton Hessian of the wdot rows of min_qddot
+            const double l0 = c.dt * vp[XW] + 2 * c.gq * rec[REC_WD], l1 = c.dt * vp[XW + 1] + 2 * c.gq * rec[REC_WD + 1],
+                         l2 = c.dt * vp[XW + 2] + 2 * c.gq * rec[REC_WD + 2];
+            for (int e = lane; e < NTRI; e += nlanes) {
+                int a = 0;
+                while ((a + 1) * (a + 2) / 2 <= e) ++a;
+                const int b = e - a * (a + 1) / 2;
+                const double* t = rec + REC_T + 3 * e;
+                double val = theta * (l0 * t[0] + l1 * t[1] + l2 * t[2]);
+                if (a >= 7 && a < 10 && b >= 3 && b < 7) {
+                    // odot = 1/2 [w;0] (x) o is bilinear in (o, w): sum_q v'_o[q] d2 odot_q / do_b dw_c = 1/2 (+-) v'_o[.], from
+                    // Jo (derivs(): rows q, columns b) = 1/2 [[0,-w2,w1,w0],[w2,0,-w0,w1],[-w1,w0,0,w2],[-w0,-w1,-w2,0]]
+                    const int ob = b - 3, cc = a - 7;
+                    double v = 0.0;
+                    for (int q = 0; q < 4; ++q) {
+                        if (q == ob) continue;
+                        int comp; double sg;
+                        if (q == 3) { comp = ob; sg = -1.0; }
+                        else if (ob == 3) { comp = q; sg = 1.0; }
+                        else { comp = 3 - q - ob; sg = ((ob - q + 3) % 3 == 1) ? -1.0 : 1.0; }
+                        if (comp == cc) v += sg * vp[XO + q];
+                    }
+                    val += 0.5 * theta * c.dt * v;
+                }
+                const int row = zcol(a), col = zcol(b);
+                Q[row * NZP + col] += val;
+                if (a != b) Q[col * NZP + row] += val;
+            }
+            return;
+        }
         for (int e = lane; e < NSO; e += nlanes) {
             const int blk = e / 9, a = (e % 9) / 3, b = e % 3;
             const int i = blk % NC;
@@ -1141,6 +1281,8 @@ using Srbd13 = SrbdModel<2, false>;
 using Srbd37 = SrbdModel<4, true>;
 using Srbd13B = SrbdModel<2, false, true>;   // with the friction-cone barrier (sddp_model_consts.friction_barrier_weight > 0)
 using Srbd37B = SrbdModel<4, true, true>;
+using Srbd13S = SrbdModel<2, false, false, true>;   // full second-order builds (sddp_options.second_order = 2)
+using Srbd37S = SrbdModel<4, true, false, true>;
 using Lip30 = LipModel;
 
 }  // namespace sddp

@@ -137,10 +137,32 @@ def _build(name, cst):
     out["ires"], out["sres"] = lam(ires_m), lam(sres_m)
     out["Ji"], out["Js"] = lam(ires_m.jacobian(z_all)), lam(sres_m.jacobian(z_all))
     out["nx"] = nx
+    out["_sym"] = (x, u, p, f, ires_m, sres_m, z_all)
     return out
 
+
 @functools.lru_cache(maxsize=None)
-def symbolic(name, inertia_mode=0, lever_sign=1.0):
+def second_order_symbolic(name, inertia_mode=0, lever_sign=1.0):
+    """lambda (x, u, p, vp) -> Hessian_z[vp.f + L_k] - 2 J^T J  (stage node k >= 1: input and state residuals), symbolic."""
+    from oracle.models import RobotConsts
+    sym = _build(name, RobotConsts(inertia_mode=inertia_mode, lever_sign=lever_sign))
+    x, u, p, f, ires_m, sres_m, z_all = sym["_sym"]
+    vp = sp.Matrix(sp.symbols(f"v0:{len(x)}"))
+    res = sp.Matrix([*ires_m, *sres_m])
+    # only the non-linear rows contribute: sum_i vp_i Hess(f_i) + sum_j 2 res_j Hess(res_j)
+    H = sp.zeros(len(z_all), len(z_all))
+    for i in range(len(x)):
+        Hi = sp.hessian(f[i], list(z_all))
+        if any(e != 0 for e in Hi):
+            H += vp[i] * Hi
+    for j in range(len(res)):
+        Hj = sp.hessian(res[j], list(z_all))
+        if any(e != 0 for e in Hj):
+            H += 2 * res[j] * Hj
+    return sp.lambdify((list(x), list(u), list(p), list(vp)), H, "numpy", cse=True)
+
+@functools.lru_cache(maxsize=None)
+def symbolic(name, inertia_mode=0, lever_sign=1.0):   # the consts object is returned so that callers can key caches on it
     from oracle.models import RobotConsts
     cst = RobotConsts(inertia_mode=inertia_mode, lever_sign=lever_sign)
     return _build(name, cst), cst

@@ -386,3 +386,51 @@ def test_friction_cone_barrier_solve_matches_oracle_and_tightens_the_cone(name, 
     assert viol["on"] < viol["off"] or viol["off"] <= 0.0, viol
     with pytest.raises(RuntimeError, match="friction"):
         DdpEngine(name, N, 1, consts=dict(friction_barrier_weight=-1.0))
+
+
+@pytest.mark.parametrize("name,N,seeds", [("srbd13", 30, [0, 1, 2, 4, 6]), ("srbd37", 20, [3, 5])])
+def test_full_second_order_mode_matches_oracle(name, N, seeds):
+    """second_order = 2 ("full DDP": v'.f_zz for the wdot and quaternion rows + exact Hessian of the wdot residual, after full
+    steps, Gauss-Newton fallback): the SO2 kernel builds against the numpy oracle, iteration by iteration."""
+    batch = workload.make_batch(name, N, seeds)
+    m = _oracle_model(name)
+    eng = DdpEngine(name, N, len(seeds), opts=_opts(second_order=2))
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    st = eng.stats.copy()
+    differs = 0
+    for b in range(len(seeds)):
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], _oracle_opts(second_order=2))
+        r1 = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], _oracle_opts(second_order=1))
+        assert st["iters"][b] == r.iters and bool(st["converged"][b]) == r.converged and st["alpha"][b] == r.alpha
+        assert np.max(np.abs(x[b] - r.xs)) <= 1e-6 and np.max(np.abs(u[b] - r.us)) <= 1e-6
+        assert abs(st["cost"][b] - r.cost) <= 1e-9 * abs(r.cost)
+        differs += int(r.iters != r1.iters)
+    assert differs > 0 or name == "srbd37"               # the mode does take another path than the default one
+    with pytest.raises(RuntimeError):
+        eng.set_options(second_order=1)                   # another kernel build and record size: create-time choice
+    with pytest.raises(RuntimeError):
+        DdpEngine(name, N, 1, opts=_opts(second_order=2), consts=dict(friction_barrier_weight=1.0))
+
+
+def test_full_second_order_whole_batch_iteration_histogram():
+    """The bench batch in second_order = 2 against the C oracle (same mode); prints the iteration histogram DESIGN.md quotes."""
+    from oracle import cport
+    N, B = 30, 1024
+    batch = workload.make_batch("srbd13", N, np.arange(B))
+    eng = DdpEngine("srbd13", N, B, opts=_opts(second_order=2))
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    st = eng.stats.copy()
+    xo, uo, so = cport.solve_batch(omodels.RobotConsts(**batch["consts"]), _oracle_opts(second_order=2), batch["x0"], batch["params"],
+                                   batch["xs"], batch["us"], threads=8)
+    it = st["iters"]
+    same = it == so[:, 1].astype(int)
+    print(f"second_order=2: GPU iterations mean {it.mean():.2f} median {np.median(it):.0f} p90 {np.percentile(it, 90):.0f} "
+          f"p99 {np.percentile(it, 99):.0f} max {it.max()}; converged {st['converged'].mean():.4f}; "
+          f"{int((~same).sum())} instances differ from the C oracle in iteration count")
+    assert same.mean() >= 0.99
+    cmp = same & (so[:, 2] == 1)
+    assert np.max(np.abs(x[cmp] - xo[cmp])) <= 1e-4 and np.max(np.abs(u[cmp] - uo[cmp])) <= 1e-4
+    np.testing.assert_allclose(st["cost"][cmp], so[cmp, 0], rtol=1e-8)
+    assert st["converged"].mean() >= 0.99 and it.mean() < 15.9          # fewer iterations than the default mode's 15.99

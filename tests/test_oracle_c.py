@@ -102,3 +102,21 @@ def test_c_solve_matches_numpy_solve_reference_models(name, N, seeds):
         assert int(st[b, 1]) == r.iters and bool(st[b, 2]) == r.converged and st[b, 3] == r.alpha and int(st[b, 6]) == r.status
         assert np.max(np.abs(xs[b] - r.xs)) <= 1e-7 and np.max(np.abs(us[b] - r.us)) <= 1e-7
         assert abs(st[b, 0] - r.cost) <= 1e-9 * abs(r.cost)
+
+
+@pytest.mark.parametrize("name,N,seeds", [("srbd13", 30, [1, 2, 4]), ("srbd37", 12, [3])])
+def test_c_full_second_order_solve_matches_numpy(name, N, seeds):
+    """second_order = 2 (v'.f_zz + exact cost Hessian after full steps): the C port takes the same path as the numpy oracle."""
+    batch = workload.make_batch(name, N, seeds)
+    cst = omodels.RobotConsts()
+    m = omodels.make_model(name, cst)
+    opts = oddp.DdpOptions(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3, second_order=2)
+    xs, us, st = cport.solve_batch(cst, opts, batch["x0"], batch["params"], batch["xs"], batch["us"], threads=2, model=name)
+    o1 = oddp.DdpOptions(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3, second_order=1)
+    _, _, st1 = cport.solve_batch(cst, o1, batch["x0"], batch["params"], batch["xs"], batch["us"], threads=2, model=name)
+    for b in range(len(seeds)):
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], opts)
+        assert int(st[b, 1]) == r.iters and bool(st[b, 2]) == r.converged and st[b, 3] == r.alpha
+        assert np.max(np.abs(xs[b] - r.xs)) <= 1e-7 and np.max(np.abs(us[b] - r.us)) <= 1e-7
+        assert abs(st[b, 0] - r.cost) <= 1e-9 * abs(r.cost)
+        assert abs(st[b, 0] - st1[b, 0]) <= 1e-6 * abs(st1[b, 0])          # the same optimum as the default mode
