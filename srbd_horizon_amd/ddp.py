@@ -125,9 +125,10 @@ class DDPSolver:
     def solve_receding(self, x0) -> bool:
         """One tick of the receding-horizon loop with device-resident data.
 
-        Contract: since the previous call the caller has shifted every parameter back by one node and assigned node N -- which
-        is all dsrbd_example.py:102-131 / wpg.py:74-99 ever do.  Then only the last parameter column and ``x0`` cross PCIe; the
-        engine shifts its resident parameter tensor and warm-starts from its previous solution advanced by one knot.  Same
+        Since the previous call the caller normally has shifted every parameter back by one node and assigned node N -- which is
+        all dsrbd_example.py:102-131 / wpg.py:74-99 ever do.  Then only the last parameter column and ``x0`` cross PCIe; the
+        engine shifts its resident parameter tensor and warm-starts from its previous solution advanced by one knot.  A host
+        shadow of the resident tensor checks that: any other change to the parameters re-uploads the whole tensor (``resyncs``).  Same
         result as ``setInitialState(x0)`` + shifted ``set_*_warmstart`` + ``solve()`` (tests/test_gpu_api.py)."""
         x0 = np.asarray(x0, dtype=float).reshape(1, self.state_size)
         self._x0 = x0.copy()
@@ -142,8 +143,21 @@ class DDPSolver:
                 self._have_x = True
             self.ddp_solver.set_params(pm[None])
             self._resident = True
+            self._shadow = pm.copy()
+            self.resyncs = 0
         else:
-            self.ddp_solver.advance(pm[-1][None], x0)
+            # host shadow of the resident tensor: the device shifts EVERY parameter column back by one node; if the caller has
+            # assigned anything else below node N since the last tick (or did not shift a parameter the device shifts), the two
+            # would drift apart silently -- re-upload the whole tensor instead (and count it: `resyncs`)
+            self._shadow[:-1] = self._shadow[1:]
+            self._shadow[-1] = pm[-1]
+            if np.array_equal(self._shadow, pm):
+                self.ddp_solver.advance(pm[-1][None], x0)
+            else:
+                self.resyncs += 1
+                self._shadow = pm.copy()
+                self.ddp_solver.advance(pm[-1][None], x0)             # warm start and state advance as usual ...
+                self.ddp_solver.set_params(pm[None])                  # ... then the parameters as the host has them
         x, u = self.ddp_solver.solve_resident()
         x, u = np.ascontiguousarray(x[0].T), np.ascontiguousarray(u[0].T)
         self.var_solution = self._createVarSolDict(x, u)

@@ -187,6 +187,20 @@ def test_device_resident_receding_horizon_equals_the_host_shift(model, ns):
         np.testing.assert_array_equal(sd["x_opt"], sh["x_opt"])
         np.testing.assert_array_equal(sd["u_opt"], sh["u_opt"])
         np.testing.assert_array_equal(dev.state, host.state)
+    assert dev.solver.resyncs == 0                                   # the example loop only shifts and assigns node N
+    # a parameter assigned BELOW node N between two ticks (nothing the reference loop does): the host shadow notices and the
+    # whole tensor is uploaded again, so the device cannot drift from the problem's parameters
+    for lp in (host, dev):
+        lp.srbd.rdot_ref.assign([0.3, -0.2, 0.0], nodes=3)
+    ch, sh = host.tick("walking", (1.0, 0.5))
+    cd, sd = dev.tick("walking", (1.0, 0.5))
+    assert dev.solver.resyncs == 1 and ch == cd
+    np.testing.assert_array_equal(sd["x_opt"], sh["x_opt"])
+    np.testing.assert_array_equal(sd["u_opt"], sh["u_opt"])
+    ch, sh = host.tick("walking", (1.0, 0.5))
+    cd, sd = dev.tick("walking", (1.0, 0.5))
+    assert dev.solver.resyncs == 1                                   # back on the shift-only path
+    np.testing.assert_array_equal(sd["x_opt"], sh["x_opt"])
     e = DdpEngine(model, ns, 1)
     with pytest.raises(RuntimeError, match="sddp_set_params"):
         e.advance(np.zeros((1, e.np_)), np.zeros((1, e.nx)))
