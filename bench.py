@@ -269,6 +269,7 @@ def main():
         del f_lat, e_lat
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out.update(single_instance_extras(N, opts, workload, DdpEngine))
+        out["ms_per_fleet_tick"] = fleet_tick(N, B, opts, workload, DdpEngine)
         # PCIe-inclusive batch rate (host-pointer C-ABI call: params in, x/u/stats out) -- reported, never `value`
         e_h = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
         e_h.set_initial_state(batch["x0"])
@@ -286,6 +287,42 @@ def main():
         print(json.dumps(out))
     if collective:
         dist.destroy_process_group()
+
+
+def fleet_tick(N, B, opts, workload, DdpEngine, ticks=24):
+    """ms / MPC tick of a FLEET: B robots, each warm-started from its previous solution advanced by one knot (sddp_advance), one
+    sddp_solve_resident per tick (results fetched to the host every tick), against the C port on the host threads for the same
+    sequence of problems.  The per-robot figure (`ms_per_mpc_tick`, B = 1) is one wavefront of the chip; this is the chip."""
+    from oracle import cport, ddp as oddp, models as omodels
+    b = workload.make_batch("srbd13", N, np.arange(B))
+    e = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
+    e.set_initial_state(b["x0"]); e.set_x_warmstart(b["xs"]); e.set_u_warmstart(b["us"])
+    e.set_params(b["params"])
+    x, u = e.solve_resident()                                  # cold solve: every robot's first tick
+    P = b["params"].copy()
+    cst, o = omodels.RobotConsts(), oddp.DdpOptions(**opts)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    gms, cms, its, same = [], [], [], []
+    for t in range(ticks):
+        p_last, x0 = P[:, -1].copy(), x[:, 1].copy()          # the plan's last column repeats; the robot is where the plan said
+        xs_ws = np.concatenate([x[:, 1:], x[:, -1:]], axis=1); xs_ws[:, 0] = x0
+        us_ws = np.concatenate([u[:, 1:], u[:, -1:]], axis=1)
+        P = np.concatenate([P[:, 1:], p_last[:, None]], axis=1)
+        t1 = time.perf_counter()
+        e.advance(p_last, x0)
+        x, u = e.solve_resident()
+        gms.append(1e3 * (time.perf_counter() - t1))
+        its.append(float(e.stats["iters"].mean()))
+        if t >= ticks - 6:                                     # CPU: the last ticks only (bounded sample)
+            t1 = time.perf_counter()
+            _, _, st = cport.solve_batch(cst, o, x0, P, xs_ws, us_ws, threads=threads)
+            cms.append(1e3 * (time.perf_counter() - t1))
+            same.append(float(np.mean(st[:, 1].astype(int) == e.stats["iters"])))
+    return {"batch": B, "gpu_ms_per_tick_median": float(np.median(gms[4:])), "gpu_ms_per_tick_p99": float(np.percentile(gms[4:], 99)),
+            "mean_iters": float(np.mean(its[4:])), "cpu_ms_per_tick_median": float(np.median(cms)), "cpu_threads": threads,
+            "same_iters_as_gpu_frac": float(np.mean(same)),
+            "note": "srbd13 N=30, every robot warm-started from its previous solution advanced by one knot; GPU tick = sddp_advance + "
+                    "sddp_solve_resident incl. the PCIe copies of p_last / x0 in and x / u / stats out; CPU = the C port, OpenMP over robots"}
 
 
 def single_instance_extras(N, opts, workload, DdpEngine):
