@@ -60,6 +60,7 @@ class MpcLoop:
         # warm start the first solve like dsrbd_example.py:61-68 computes it (x = state at every node, u = static input)
         self.solver.set_x_warmstart(np.repeat(self.state[:, None], ns + 1, axis=1))
         self.solver.set_u_warmstart(np.repeat(self.srbd.getStaticInput()[:, None], ns, axis=1))
+        self._prev_sw = [1.0, 1.0]     # srbd13: contact switch of each foot at node ns after the previous tick (touchdown detection)
         self.solve_ms = []
         self.trace = None          # set to a list to record every tick's solver inputs (x0, params, warm start): bench.py replays them
         self._last = None
@@ -74,6 +75,19 @@ class MpcLoop:
         a = 0.1 if motion == "standing" else 0.5                                       # :109-112
         s.rdot_ref.assign([a * axes[0], a * axes[1], 0.0], nodes=ns)                   # :119-122
         self.wpg.set({"walking": "step", "jumping": "jump"}.get(motion, "standing"))   # :126-131
+        if self.model == "srbd13":
+            # The metric model's contacts are per-knot DATA, so the footstep plan has to ride with the horizon
+            # like every other parameter (the reference's contacts are states and move by themselves): shift the xy rows, repeat the
+            # last node, and at a touchdown (switch 0 -> 1 at node ns) move that foot one stride = commanded velocity x 1 s step
+            # cycle ahead -- the plan of workload.schedule_by_ticking, which the bench batch is built from
+            stride = np.array([a * axes[0], a * axes[1]]) * 1.0
+            for i in range(2):
+                cxy = s.c[i].values
+                cxy[0:2, :ns] = cxy[0:2, 1:ns + 1]
+                sw_new = float(s.cdot_switch[i].values[0, ns])
+                if self._prev_sw[i] == 0.0 and sw_new == 1.0:
+                    cxy[0:2, ns] = cxy[0:2, ns - 1] + stride
+                self._prev_sw[i] = sw_new
         if self.trace is not None:
             self.trace.append(self._solver_inputs())
         t0 = time.perf_counter()                                                       # :134 tic()
