@@ -339,8 +339,8 @@ static void s13_core(const consts_t* c, const double* x, const double* u, const 
     core_n(c, x, x + 3, x + 10, 2, cs, fs, k);
     if (J) corejac_n(c, x, x + 3, x + 10, 2, cs, fs, k, J);
 }
-static void s13_dyn(const consts_t* c, const double* x, const double* u, const double* p, double* xn) {
-    core_t k; s13_core(c, x, u, p, &k, NULL);
+static void s13_dyn_k(const consts_t* c, const double* x, const core_t* kp, double* xn) {
+    const core_t k = *kp;
     const double dt = c->dt;
     double on[4]; quat_step(x + 3, x + 10, dt, on);
     for (int a = 0; a < 3; ++a) {
@@ -350,6 +350,10 @@ static void s13_dyn(const consts_t* c, const double* x, const double* u, const d
         xn[10 + a] = w + dt * k.wdot[a];
     }
     for (int a = 0; a < 4; ++a) xn[3 + a] = on[a];
+}
+static void s13_dyn(const consts_t* c, const double* x, const double* u, const double* p, double* xn) {
+    core_t k; s13_core(c, x, u, p, &k, NULL);
+    s13_dyn_k(c, x, &k, xn);
 }
 static void s13_wrows(const corejac_t* Jc, double g, double* M, int nz, int row0) {   /* rows of d wdot/dz scaled by g */
     for (int a = 0; a < 3; ++a) {
@@ -370,12 +374,13 @@ static void s13_dyn_jac(const consts_t* c, const double* x, const double* u, con
     s13_wrows(&Jc, dt, F, nz, 10);
     quat_jac(x + 3, x + 10, dt, F, nz, 3, 10);
 }
-static int s13_residual(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J) {
+static int s13_residual_k(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J, const core_t* pre) {
     int n = 0; const int nz = 19;
     if (J) memset(J, 0, sizeof(double) * NR * nz);
     if (!u || k >= 1) n = srbd_state_rows(c, x, 0, 3, 7, 10, p, p + 3, p[6], p + 7, r, J, nz, n);
     if (u) {
-        core_t kk; corejac_t Jc; s13_core(c, x, u, p, &kk, J ? &Jc : NULL);
+        core_t kk; corejac_t Jc;
+        if (pre && !J) kk = *pre; else s13_core(c, x, u, p, &kk, J ? &Jc : NULL);
         const double g = sqrt(c->gq);
         for (int a = 0; a < 3; ++a) { r[n + a] = g * kk.rddot[a]; r[n + 3 + a] = g * kk.wdot[a]; }
         if (J) {
@@ -386,6 +391,17 @@ static int s13_residual(const consts_t* c, const double* x, const double* u, con
         for (int i = 0; i < 2; ++i) n = force_rows(c, u + 3 * i, p[17 + i], 13 + 3 * i, r, J, nz, n);
     }
     return n;
+}
+static int s13_residual(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J) {
+    return s13_residual_k(c, x, u, p, k, r, J, NULL);
+}
+/* one rollout knot: cost of node k at (x, u) and x+ = f(x, u), the accelerations evaluated once for both */
+static double s13_stepcost(const consts_t* c, const double* x, const double* u, const double* p, int k, double* xn) {
+    core_t kk; s13_core(c, x, u, p, &kk, NULL);
+    double r[NR]; const int n = s13_residual_k(c, x, u, p, k, r, NULL, &kk);
+    double s = 0; for (int i = 0; i < n; ++i) s += r[i] * r[i];
+    s13_dyn_k(c, x, &kk, xn);
+    return s;
 }
 /* exact bilinear-torque term: Qux[f_a][r_b] -= theta * s * skew(y)[a][b], y = I_w^-1 (dt v'_w)   */
 static void s13_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, int mode,
@@ -426,9 +442,8 @@ static void s37_core(const consts_t* c, const double* x, const double* u, core_t
     core_n(c, x, x + 3, x + 22, 4, cs, fs, k);
     if (J) corejac_n(c, x, x + 3, x + 22, 4, cs, fs, k, J);
 }
-static void s37_dyn(const consts_t* c, const double* x, const double* u, const double* p, double* xn) {
-    (void)p;
-    core_t k; s37_core(c, x, u, &k, NULL);
+static void s37_dyn_k(const consts_t* c, const double* x, const double* u, const core_t* kp, double* xn) {
+    const core_t k = *kp;
     const double dt = c->dt;
     double on[4], tmp[37]; quat_step(x + 3, x + 22, dt, on);
     for (int a = 0; a < 3; ++a) {
@@ -442,6 +457,11 @@ static void s37_dyn(const consts_t* c, const double* x, const double* u, const d
         tmp[25 + 3 * i + a] = x[25 + 3 * i + a] + dt * u[6 * i + a];
     }
     memcpy(xn, tmp, sizeof(tmp));
+}
+static void s37_dyn(const consts_t* c, const double* x, const double* u, const double* p, double* xn) {
+    (void)p;
+    core_t k; s37_core(c, x, u, &k, NULL);
+    s37_dyn_k(c, x, u, &k, xn);
 }
 static void s37_wrows(const corejac_t* Jc, double g, double* M, int nz, int row0) {
     for (int a = 0; a < 3; ++a) {
@@ -470,7 +490,7 @@ static void s37_dyn_jac(const consts_t* c, const double* x, const double* u, con
     s37_wrows(&Jc, dt, F, nz, 22);
     quat_jac(x + 3, x + 22, dt, F, nz, 3, 22);
 }
-static int s37_residual(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J) {
+static int s37_residual_k(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J, const core_t* pre) {
     int n = 0; const int nz = 61;
     if (J) memset(J, 0, sizeof(double) * NR * nz);
     if (!u || k >= 1) {
@@ -478,7 +498,8 @@ static int s37_residual(const consts_t* c, const double* x, const double* u, con
         n = rel_pos_rows(c, x, S37_C, r, J, nz, n);
     }
     if (u) {
-        core_t kk; corejac_t Jc; s37_core(c, x, u, &kk, J ? &Jc : NULL);
+        core_t kk; corejac_t Jc;
+        if (pre && !J) kk = *pre; else s37_core(c, x, u, &kk, J ? &Jc : NULL);
         const double g = sqrt(c->gq);
         for (int a = 0; a < 3; ++a) { r[n + a] = g * kk.rddot[a]; r[n + 3 + a] = g * kk.wdot[a]; }
         for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) { r[n + 6 + 3 * i + a] = g * u[6 * i + a]; if (J) J[(n + 6 + 3 * i + a) * nz + 37 + 6 * i + a] = g; }
@@ -493,6 +514,16 @@ static int s37_residual(const consts_t* c, const double* x, const double* u, con
         n = contact_penalty_rows(x, S37_C, S37_CD, cref, sw, r, J, nz, n);
     }
     return n;
+}
+static int s37_residual(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J) {
+    return s37_residual_k(c, x, u, p, k, r, J, NULL);
+}
+static double s37_stepcost(const consts_t* c, const double* x, const double* u, const double* p, int k, double* xn) {
+    core_t kk; s37_core(c, x, u, &kk, NULL);
+    double r[NR]; const int n = s37_residual_k(c, x, u, p, k, r, NULL, &kk);
+    double s = 0; for (int i = 0; i < n; ++i) s += r[i] * r[i];
+    s37_dyn_k(c, x, u, &kk, xn);
+    return s;
 }
 static void s37_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, int mode,
                              double* Q) {
@@ -591,6 +622,12 @@ static int l30_residual(const consts_t* c, const double* x, const double* u, con
         n = contact_penalty_rows(x, L30_C, L30_CD, cref, sw, r, J, nz, n);
     }
     return n;
+}
+static double l30_stepcost(const consts_t* c, const double* x, const double* u, const double* p, int k, double* xn) {
+    double r[NR]; const int n = l30_residual(c, x, u, p, k, r, NULL);
+    double s = 0; for (int i = 0; i < n; ++i) s += r[i] * r[i];
+    l30_dyn(c, x, u, p, xn);
+    return s;
 }
 static void l30_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, int mode,
                              double* Q) {
