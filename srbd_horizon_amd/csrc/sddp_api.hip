@@ -278,6 +278,11 @@ int validate_options(sddp_handle* h, const sddp_options& o) {
     for (double v : fin)
         if (!std::isfinite(v)) return fail(h, SDDP_ERR_ARG, "non-finite value in sddp_options");
     if (!(o.mu_max > o.mu_min)) return fail(h, SDDP_ERR_ARG, "mu_max must be > mu_min");
+    // the line-search ladder alpha_0 * factor^j down to alpha_converge_threshold is rolled out inside the kernel: bound its length
+    if (o.alpha_converge_threshold < o.alpha_0 &&
+        std::log(o.alpha_converge_threshold / o.alpha_0) / std::log(o.line_search_decrease_factor) > 4096.0)
+        return fail(h, SDDP_ERR_ARG, "line search ladder longer than 4096 step lengths (line_search_decrease_factor too close to 1 "
+                                     "or alpha_converge_threshold too small)");
     if (o.queue_order != 0 && o.queue_order != 1) return fail(h, SDDP_ERR_ARG, "queue_order must be 0 or 1");
     if (o.second_order < 0 || o.second_order > 2) return fail(h, SDDP_ERR_ARG, "second_order must be 0, 1 or 2");
     return SDDP_OK;

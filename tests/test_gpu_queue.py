@@ -94,7 +94,7 @@ def test_ranges_of_a_handle_solve_like_separate_batches():
 
 def test_non_finite_options_are_rejected():
     for k, v in (("alpha_0", float("inf")), ("mu_max", float("nan")), ("beta", float("nan")), ("gap_tol", float("inf")),
-                 ("mu_max", 1e-7), ("queue_order", 2)):
+                 ("mu_max", 1e-7), ("queue_order", 2), ("line_search_decrease_factor", 0.9999999), ("second_order", 3)):
         with pytest.raises(RuntimeError):
             DdpEngine("srbd13", 30, 1, opts=dict(OPTS, **{k: v}))
 
