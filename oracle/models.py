@@ -209,7 +209,10 @@ def srbd_acc(cst: RobotConsts, r, o, w, cs, fs):
     rddot = np.array([0.0, 0.0, -GRAVITY]) + sum(fs) / ms
     M, _ = world_inertia(cst, o)
     tau = sum(cst.lever_sign * np.cross(c - r, f) for c, f in zip(cs, fs)) - np.cross(w, M @ w)
-    wdot = np.linalg.solve(M, tau)
+    try:
+        wdot = np.linalg.solve(M, tau)
+    except np.linalg.LinAlgError:            # a diverged line-search candidate (inf / nan state): its cost must come out non-finite,
+        wdot = np.full(3, np.nan)            # not as an exception (the C oracle and the kernels divide and carry on)
     return rddot, wdot
 
 
@@ -218,7 +221,10 @@ def srbd_acc_jac(cst: RobotConsts, r, o, w, cs, fs):
     rddot_f (scalar 1/ms: d rddot / d f_i = I/ms)."""
     ms = cst.m / cst.force_scaling
     M, dM = world_inertia(cst, o)
-    Minv = np.linalg.inv(M)
+    try:
+        Minv = np.linalg.inv(M)
+    except np.linalg.LinAlgError:            # diverged line-search candidate: non-finite results, no exception (see srbd_acc)
+        Minv = np.full((3, 3), np.nan)
     tau = sum(cst.lever_sign * np.cross(c - r, f) for c, f in zip(cs, fs)) - np.cross(w, M @ w)
     wdot = Minv @ tau
     s = cst.lever_sign

@@ -433,6 +433,24 @@ def test_full_second_order_mode_matches_oracle(name, N, seeds):
         DdpEngine(name, N, 1, opts=_opts(second_order=2), consts=dict(friction_barrier_weight=1.0))
 
 
+@pytest.mark.parametrize("name,N,consts", [("srbd13", 30, dict(inertia_mode=1)), ("srbd13", 4, dict(inertia_mode=1, lever_sign=-1.0)),
+                                           ("srbd13", 2, {}), ("srbd13", 1, {}), ("srbd37", 3, dict(inertia_mode=1))])
+def test_full_second_order_mode_other_constants_and_short_horizons(name, N, consts):
+    """second_order = 2 with the physical inertia rotation R I R^T / the other lever-arm sign (the second derivatives of I_w take
+    another branch), and on horizons of one to three knots."""
+    seeds = [2, 9]
+    batch = workload.make_batch(name, N, seeds)
+    m = _oracle_model(name, consts)
+    eng = DdpEngine(name, N, len(seeds), opts=_opts(second_order=2), consts=dict(batch["consts"], **consts))
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    for b in range(len(seeds)):
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], _oracle_opts(second_order=2))
+        assert eng.stats["iters"][b] == r.iters and bool(eng.stats["converged"][b]) == r.converged
+        assert np.max(np.abs(x[b] - r.xs)) <= 1e-6 and np.max(np.abs(u[b] - r.us)) <= 1e-6
+        assert abs(eng.stats["cost"][b] - r.cost) <= 1e-9 * abs(r.cost)
+
+
 def test_full_second_order_whole_batch_iteration_histogram():
     """The bench batch in second_order = 2 against the C oracle (same mode); prints the iteration histogram DESIGN.md quotes."""
     from oracle import cport
