@@ -451,6 +451,25 @@ def test_full_second_order_mode_other_constants_and_short_horizons(name, N, cons
         assert abs(eng.stats["cost"][b] - r.cost) <= 1e-9 * abs(r.cost)
 
 
+@pytest.mark.parametrize("name,N,consts,so", [("srbd13", 30, dict(inertia_mode=1), 1), ("srbd13", 30, dict(inertia_mode=1), 0),
+                                              ("srbd37", 20, dict(inertia_mode=1), 1), ("srbd13", 6, dict(lever_sign=-1.0), 1)])
+def test_converged_solves_with_the_optional_model_conventions(name, N, consts, so):
+    """The two upstream-unverified conventions as options: physical inertia rotation R I R^T instead of the
+    reference's element-wise product, and the other lever-arm sign -- whole solves against the numpy oracle."""
+    seeds = [1, 5, 8]
+    batch = workload.make_batch(name, N, seeds)
+    m = _oracle_model(name, consts)
+    eng = DdpEngine(name, N, len(seeds), opts=_opts(second_order=so), consts=dict(batch["consts"], **consts))
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    for b in range(len(seeds)):
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], _oracle_opts(second_order=so))
+        assert eng.stats["iters"][b] == r.iters and bool(eng.stats["converged"][b]) == r.converged and eng.stats["status"][b] == r.status
+        if r.converged:
+            assert np.max(np.abs(x[b] - r.xs)) <= 1e-6 and np.max(np.abs(u[b] - r.us)) <= 1e-6
+            assert abs(eng.stats["cost"][b] - r.cost) <= 1e-9 * abs(r.cost)
+
+
 def test_full_second_order_whole_batch_iteration_histogram():
     """The bench batch in second_order = 2 against the C oracle (same mode); prints the iteration histogram DESIGN.md quotes."""
     from oracle import cport
