@@ -51,7 +51,7 @@ typedef struct sddp_options {
                                            once full steps are accepted.  2: full second-order DDP -- the whole
                                            dynamics tensor v'.f_zz (second derivatives of wdot and of the quaternion kinematics) and the
                                            exact instead of the Gauss-Newton Hessian of the wdot residual, same schedule and fallback;
-                                           selects its own kernel build at sddp_create (not with the friction barrier) */
+                                           selects its own kernel build at sddp_create */
     int    waves_per_simd;              /* scheduling hint, no effect on results.  1 (default): the kernel build with the full
                                            register file per instance -- shortest time for ONE batch.  2: the build capped at
                                            half the register file, two instances resident per SIMD -- highest solves/s when

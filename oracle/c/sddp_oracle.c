@@ -222,6 +222,17 @@ static void srbd_second_order_full(const consts_t* c, const double* r, const dou
     memset(S, 0, sizeof(double) * n * n);
     wdot_hess_contract(c, r, o, w, nc, cs, fs, lam, S);
     for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) if (gl[a] >= 0 && gl[b] >= 0) Q[gl[a] * nz + gl[b]] += theta * S[a * n + b];
+    if (c->bar_w > 0.0) {   /* friction-cone barrier: exact - Gauss-Newton Hessian = (w s^2 / 2) sum_j e_j a_j a_j^T once more */
+        const double ml = c->mu_lin;
+        const double A[5][3] = {{1, 0, -ml}, {-1, 0, -ml}, {0, 1, -ml}, {0, -1, -ml}, {0, 0, -1}};
+        for (int i = 0; i < nc; ++i) {
+            const int f0 = gl[10 + 3 * nc + 3 * i];
+            for (int j = 0; j < 5; ++j) {
+                const double e = c->bar_w * exp(c->bar_s * (A[j][0] * fs[i][0] + A[j][1] * fs[i][1] + A[j][2] * fs[i][2]));
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) Q[(f0 + a) * nz + f0 + b] += theta * 0.5 * c->bar_s * c->bar_s * e * A[j][a] * A[j][b];
+            }
+        }
+    }
     for (int cc = 0; cc < 3; ++cc) {                     /* odot bilinear in (o, w): d(d odot/d o)/dw_c = Jo at w = e_c */
         double e[3] = {0, 0, 0}; e[cc] = 1.0;
         const double Jo[16] = {0, -0.5 * e[2], 0.5 * e[1], 0.5 * e[0], 0.5 * e[2], 0, -0.5 * e[0], 0.5 * e[1],

@@ -446,6 +446,14 @@ def _srbd_second_order_full(cst, nz, r, o, w, cs, fs, vp_o, vp_w, o0, w0, c_idx,
     Q = cst.dt * quat_rate_hess_contract(vp_o)
     S[o0:o0 + 4, w0:w0 + 3] += Q
     S[w0:w0 + 3, o0:o0 + 4] += Q.T
+    if cst.friction_barrier_weight > 0.0:
+        # opt-in friction-cone barrier (_force_rows): cost w sum_j exp(s a_j.f) has the exact Hessian w s^2 e_j a_j a_j^T, its
+        # residual form r_j = sqrt(w) exp(s a_j.f / 2) the Gauss-Newton Hessian (w s^2 / 2) e_j a_j a_j^T: the difference is the same again
+        A = friction_cone_rows(cst.friction_cone_coefficient)
+        for i in range(nc):
+            e = cst.friction_barrier_weight * np.exp(cst.friction_barrier_sharpness * (A @ fs[i]))
+            H = 0.5 * cst.friction_barrier_sharpness ** 2 * (A.T * e) @ A
+            S[f_idx[i]:f_idx[i] + 3, f_idx[i]:f_idx[i] + 3] += H
     return S
 
 

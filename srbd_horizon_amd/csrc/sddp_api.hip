@@ -30,8 +30,8 @@ struct Dims {
 // bar: the friction-cone barrier build of the SRBD models, so2: the full second-order build (longer derivative records)
 bool model_dims(int id, Dims& d, bool bar = false, bool so2 = false) {
     switch (id) {
-        case SDDP_MODEL_SRBD13: d = {Srbd13::NX, Srbd13::NU, Srbd13::NP, so2 ? Srbd13S::NREC : (bar ? Srbd13B::NREC : Srbd13::NREC), Lds<Srbd13>::BYTES}; return true;
-        case SDDP_MODEL_SRBD37: d = {Srbd37::NX, Srbd37::NU, Srbd37::NP, so2 ? Srbd37S::NREC : (bar ? Srbd37B::NREC : Srbd37::NREC), Lds<Srbd37>::BYTES}; return true;
+        case SDDP_MODEL_SRBD13: d = {Srbd13::NX, Srbd13::NU, Srbd13::NP, so2 ? (bar ? Srbd13BS::NREC : Srbd13S::NREC) : (bar ? Srbd13B::NREC : Srbd13::NREC), Lds<Srbd13>::BYTES}; return true;
+        case SDDP_MODEL_SRBD37: d = {Srbd37::NX, Srbd37::NU, Srbd37::NP, so2 ? (bar ? Srbd37BS::NREC : Srbd37S::NREC) : (bar ? Srbd37B::NREC : Srbd37::NREC), Lds<Srbd37>::BYTES}; return true;
         case SDDP_MODEL_LIP30: d = {Lip30::NX, Lip30::NU, Lip30::NP, Lip30::NREC, Lds<Lip30>::BYTES}; return true;
         default: return false;
     }
@@ -249,8 +249,8 @@ int launch_model_step(sddp_handle* h, int k, const double* dx, const double* du,
 
 #define DISPATCH(h, fn, ...)                                                 \
     switch ((h)->model_id) {                                                 \
-        case SDDP_MODEL_SRBD13: rc = (h)->so2 ? fn<Srbd13S>(__VA_ARGS__) : ((h)->bar ? fn<Srbd13B>(__VA_ARGS__) : fn<Srbd13>(__VA_ARGS__)); break; \
-        case SDDP_MODEL_SRBD37: rc = (h)->so2 ? fn<Srbd37S>(__VA_ARGS__) : ((h)->bar ? fn<Srbd37B>(__VA_ARGS__) : fn<Srbd37>(__VA_ARGS__)); break; \
+        case SDDP_MODEL_SRBD13: rc = (h)->so2 ? ((h)->bar ? fn<Srbd13BS>(__VA_ARGS__) : fn<Srbd13S>(__VA_ARGS__)) : ((h)->bar ? fn<Srbd13B>(__VA_ARGS__) : fn<Srbd13>(__VA_ARGS__)); break; \
+        case SDDP_MODEL_SRBD37: rc = (h)->so2 ? ((h)->bar ? fn<Srbd37BS>(__VA_ARGS__) : fn<Srbd37S>(__VA_ARGS__)) : ((h)->bar ? fn<Srbd37B>(__VA_ARGS__) : fn<Srbd37>(__VA_ARGS__)); break; \
         case SDDP_MODEL_LIP30: rc = fn<Lip30>(__VA_ARGS__); break;            \
         default: rc = SDDP_ERR_MODEL;                                         \
     }
@@ -350,7 +350,6 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     Dims d;
     const bool bar = consts && consts->friction_barrier_weight > 0.0 && model_id != SDDP_MODEL_LIP30;
     const bool so2 = opts && opts->second_order == 2 && model_id != SDDP_MODEL_LIP30;     // (the LIP model is linear-quadratic: nothing to add)
-    if (bar && so2) return fail(nullptr, SDDP_ERR_ARG, "second_order = 2 is not available together with the friction-cone barrier");
     if (!model_dims(model_id, d, bar, so2)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
     if (N < 1 || batch < 1) return fail(nullptr, SDDP_ERR_ARG, "N and batch must be >= 1");
     if (consts && (consts->friction_barrier_weight < 0.0 || (bar && !(consts->friction_cone_coefficient > 0.0))))

@@ -966,6 +966,8 @@ struct SrbdModel {
                     }
                     val += 0.5 * theta * c.dt * v;
                 }
+                if (BAR && a >= AF && b >= AF && (a - AF) / 3 == (b - AF) / 3)   // barrier: exact - Gauss-Newton Hessian = its GN block once more
+                    val += theta * barrier_h(rec + REC_B + 5 * ((a - AF) / 3), (a - AF) % 3, (b - AF) % 3);
                 const int row = zcol(a), col = zcol(b);
                 Q[row * NZP + col] += val;
                 if (a != b) Q[col * NZP + row] += val;
@@ -1283,6 +1285,8 @@ using Srbd13B = SrbdModel<2, false, true>;   // with the friction-cone barrier (
 using Srbd37B = SrbdModel<4, true, true>;
 using Srbd13S = SrbdModel<2, false, false, true>;   // full second-order builds (sddp_options.second_order = 2)
 using Srbd37S = SrbdModel<4, true, false, true>;
+using Srbd13BS = SrbdModel<2, false, true, true>;    // barrier + full second order
+using Srbd37BS = SrbdModel<4, true, true, true>;
 using Lip30 = LipModel;
 
 }  // namespace sddp

@@ -429,15 +429,16 @@ def test_full_second_order_mode_matches_oracle(name, N, seeds):
     assert differs > 0 or name == "srbd37"               # the mode does take another path than the default one
     with pytest.raises(RuntimeError):
         eng.set_options(second_order=1)                   # another kernel build and record size: create-time choice
-    with pytest.raises(RuntimeError):
-        DdpEngine(name, N, 1, opts=_opts(second_order=2), consts=dict(friction_barrier_weight=1.0))
 
 
 @pytest.mark.parametrize("name,N,consts", [("srbd13", 30, dict(inertia_mode=1)), ("srbd13", 4, dict(inertia_mode=1, lever_sign=-1.0)),
-                                           ("srbd13", 2, {}), ("srbd13", 1, {}), ("srbd37", 3, dict(inertia_mode=1))])
+                                           ("srbd13", 2, {}), ("srbd13", 1, {}), ("srbd37", 3, dict(inertia_mode=1)),
+                                           ("srbd13", 30, dict(friction_barrier_weight=2.0, friction_barrier_sharpness=4.0)),
+                                           ("srbd37", 10, dict(friction_barrier_weight=2.0, friction_barrier_sharpness=4.0))])
 def test_full_second_order_mode_other_constants_and_short_horizons(name, N, consts):
     """second_order = 2 with the physical inertia rotation R I R^T / the other lever-arm sign (the second derivatives of I_w take
-    another branch), and on horizons of one to three knots."""
+    another branch), on horizons of one to four knots, and together with the opt-in friction-cone barrier (whose exact Hessian is
+    twice its Gauss-Newton one)."""
     seeds = [2, 9]
     batch = workload.make_batch(name, N, seeds)
     m = _oracle_model(name, consts)

@@ -104,11 +104,11 @@ def test_c_solve_matches_numpy_solve_reference_models(name, N, seeds):
         assert abs(st[b, 0] - r.cost) <= 1e-9 * abs(r.cost)
 
 
-@pytest.mark.parametrize("name,N,seeds", [("srbd13", 30, [1, 2, 4]), ("srbd37", 12, [3])])
-def test_c_full_second_order_solve_matches_numpy(name, N, seeds):
+@pytest.mark.parametrize("name,N,seeds,bar", [("srbd13", 30, [1, 2, 4], 0.0), ("srbd37", 12, [3], 0.0), ("srbd13", 30, [2], 2.0)])
+def test_c_full_second_order_solve_matches_numpy(name, N, seeds, bar):
     """second_order = 2 (v'.f_zz + exact cost Hessian after full steps): the C port takes the same path as the numpy oracle."""
     batch = workload.make_batch(name, N, seeds)
-    cst = omodels.RobotConsts()
+    cst = omodels.RobotConsts(friction_barrier_weight=bar, friction_barrier_sharpness=4.0)
     m = omodels.make_model(name, cst)
     opts = oddp.DdpOptions(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3, second_order=2)
     xs, us, st = cport.solve_batch(cst, opts, batch["x0"], batch["params"], batch["xs"], batch["us"], threads=2, model=name)

@@ -187,11 +187,12 @@ def test_friction_cone_barrier_rows(name):
     assert on.residual_jac(x, None, p, 5)[0].shape == off.residual_jac(x, None, p, 5)[0].shape
 
 
-@pytest.mark.parametrize("name,imode,lever", [("srbd13", 0, 1.0), ("srbd13", 1, -1.0), ("srbd37", 0, 1.0), ("srbd37", 1, 1.0)])
-def test_full_second_order_term_matches_finite_differences(name, imode, lever):
+@pytest.mark.parametrize("name,imode,lever,bar", [("srbd13", 0, 1.0, 0.0), ("srbd13", 1, -1.0, 0.0), ("srbd37", 0, 1.0, 0.0), ("srbd37", 1, 1.0, 0.0),
+                                                  ("srbd13", 0, 1.0, 3.0), ("srbd37", 0, 1.0, 3.0)])
+def test_full_second_order_term_matches_finite_differences(name, imode, lever, bar):
     """second_order_full (second_order = 2) = Hessian of v'.f(z) + (exact Hessian of L_k - its Gauss-Newton part), over
     z = [x u]: central differences of the analytic first derivatives (F^T v' and the cost gradient) give the same matrix."""
-    m = models.make_model(name, models.RobotConsts(inertia_mode=imode, lever_sign=lever))
+    m = models.make_model(name, models.RobotConsts(inertia_mode=imode, lever_sign=lever, friction_barrier_weight=bar, friction_barrier_sharpness=3.0))
     rng = np.random.default_rng(21)
     x, u, p = _rand_point(m, rng)
     vp = rng.standard_normal(m.nx)
