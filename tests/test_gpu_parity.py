@@ -326,6 +326,8 @@ def test_whole_bench_batch_matches_the_c_oracle():
                                    batch["xs"], batch["us"], threads=8)
     it_o = so[:, 1].astype(int)
     same = st["iters"] == it_o
+    print(f"bench batch: {int((~same).sum())} of {B} instances with a different iteration count than the C oracle "
+          f"(GPU {st['iters'][~same].tolist()} oracle {it_o[~same].tolist()}); max l-inf x {np.max(np.abs(x[same] - xo[same])):.2e}")
     # chaotic early iterations of a few hard instances may pick another step length on a last-bit difference: allow 1 %
     assert same.mean() >= 0.99, f"{(~same).sum()} instances with a different iteration count"
     assert st["iters"].max() >= 60 and st["rollouts"].max() > st["iters"].max()       # the fallback path did run
@@ -334,6 +336,11 @@ def test_whole_bench_batch_matches_the_c_oracle():
     assert ex.max() <= 1e-4 and eu.max() <= 1e-4, (ex.max(), eu.max())
     np.testing.assert_allclose(st["cost"][same], so[same, 0], rtol=1e-8)
     np.testing.assert_array_equal(st["converged"][same], so[same, 2].astype(int))
+    # the instances on another path are not dropped from the check: finite, same convergence flag, same optimum
+    d = ~same
+    assert np.all(np.isfinite(x[d])) and np.all(np.isfinite(u[d]))
+    np.testing.assert_array_equal(st["converged"][d], so[d, 2].astype(int))
+    np.testing.assert_allclose(st["cost"][d], so[d, 0], rtol=1e-5)
 
 
 @pytest.mark.parametrize("name,N,B", [("srbd13", 1, 3), ("srbd13", 2, 1), ("srbd13", 100, 2), ("lip30", 1, 2), ("srbd37", 2, 2),
