@@ -8,16 +8,20 @@
 A "step" is one pass of the hot path over one batch of synthetic input: B = 1024 independent SRBD MPC instances per
 GPU (BASELINE configs[2]; 8 GPUs x 1024 = configs[3]), N = 30 knots, nx = 13, nu = 6, each solved from a cold
 warm start (x = x0 at every node, u = static input) to convergence with the reference example's solver options
-(dsrbd_example.py:55-58).  Inputs are resident in HBM before the timed region; a step = reset of the batch's initial state and
-warm start (D2D) + its instances entering the engine's work queue (srbd_horizon_amd/fleet.py).  The queue is solved by ONE
-launch per `--queue-depth` steps (and at the end of the timed region): the resident wavefronts of the device (2 per SIMD =
-2048) pull instances until the queue is empty (+ the RCCL all-gather of the solution records when N > 1), on ONE stream.
+(dsrbd_example.py:55-58).  EVERY step solves instances of its own (seed block rank * steps + step; the warm-up steps use
+further blocks), so nothing solved in the timed region has been seen before.  Inputs are resident in HBM before the timed
+region; a step = that batch's initial state, warm start and parameters (D2D) entering the engine's work queue
+(srbd_horizon_amd/fleet.py).  The queue is solved by ONE launch per `--queue-depth` steps (and at the end of the timed region):
+the resident wavefronts of the device (2 per SIMD = 2048) pull instances until the queue is empty (+ the asynchronous RCCL
+all-gather of the solution records when N > 1), on ONE stream.
 
-Why a queue: a batch ends with its slowest instance (93 DDP iterations; the mean is 16) and 1024 instances do not fill 2048
-wavefront slots, so one launch per batch leaves most SIMD time idle.  The queue is ordered longest-previous-solve-first
-(sddp_options.queue_order, include/sddp.h): in this bench every step re-solves the same synthetic batch, so the order hint
-from the priming pass is exact -- the figure with plain index order is reported beside it (`index_order_solves_per_s`), and
-the strictly sequential one-batch-per-launch figure as `one_batch_in_flight_*`.  Weak scaling.
+Why a queue: a batch ends with its slowest instance (up to 100 DDP iterations; the mean is 16) and 1024 instances do not fill
+2048 wavefront slots, so one launch per batch leaves most SIMD time idle.  A launch of a queue still ends with its slowest
+instance, so the order matters.  `value` is measured with `queue_order = 2`: a pre-pass of the launch evaluates every
+instance's initial cost and the queue starts the costliest warm starts first -- no history, no foreknowledge.  Reported beside
+it: plain index order, and `replay_history_order_solves_per_s` = longest-previous-solve-first on a handle that HAS solved the
+same instances once before (exact foreknowledge: the upper bound a fleet of recurring robots approaches; round 2's headline),
+and the strictly sequential one-batch-per-launch figure as `one_batch_in_flight_*`.  Weak scaling.
 
 Rank 0 prints ONE JSON line; `roofline` and `cpu_baseline` are defined in DESIGN.md ("Measurement").
 """
@@ -111,18 +115,33 @@ def cpu_tick_baseline(model, trace, gpu_iters):
             "sample": f"{len(trace)} recorded ticks, each solved from the same x0 / parameters / warm start as the GPU tick"}
 
 
+def seed_block(rank, world, steps, warmup, phase, i):
+    """Block of instance seeds (block b = seeds b*B .. b*B+B-1) a step solves.  Timed step i of rank r: block r*steps + i (the
+    ranks shard the timed instances contiguously); warm-up step i of rank r: block world*steps + r*warmup + i.  No instance of
+    the timed region is ever solved before the timed region starts (tests/test_bench_accounting.py)."""
+    if phase == "timed":
+        assert 0 <= i < steps
+        return rank * steps + i
+    assert phase == "warmup" and 0 <= i < warmup
+    return world * steps + rank * warmup + i
+
+
+ORDER_NAMES = {0: "index", 1: "longest previous solve first (history of this handle)", 2: "largest initial cost first (pre-pass of the launch, no history)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=192)
-    ap.add_argument("--warmup", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=1024, help="MPC instances per GPU and step")
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the single-instance extras")
     ap.add_argument("--queue-depth", type=int, default=64, help="steps (batches) one engine handle holds = most steps per launch")
     ap.add_argument("--waves-per-simd", type=int, default=2, help="kernel build: 1 = one wavefront per SIMD, 2 = two")
-    ap.add_argument("--queue-order", type=int, default=1, help="1: longest previous solve first (sddp_options.queue_order), 0: index order")
-    ap.add_argument("--no-extras", action="store_true", help="skip the index-order and one-batch-in-flight measurements")
+    ap.add_argument("--queue-order", type=int, default=2, help="sddp_options.queue_order: 2 largest initial cost first (no history), "
+                                                              "0 index order, 1 longest previous solve first (needs history)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the index-order, replay and one-batch-in-flight measurements")
     args = ap.parse_args()
 
     import torch
@@ -156,52 +175,71 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     N, B = args.horizon, args.batch
-    Q = max(1, min(args.queue_depth, max(args.steps, 1)))
+    steps, warmup = max(args.steps, 1), max(args.warmup, 0)
+    Q = max(1, min(args.queue_depth, steps))
     nx, nu, npar = 13, 6, 19
-    seeds = rank * B + np.arange(B)                        # instances are sharded contiguously across ranks
-    batch = workload.make_batch("srbd13", N, seeds)
     opts = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsrbd_example.py:55-58
     wps = args.waves_per_simd
-    d_x0 = torch.from_numpy(batch["x0"]).to(dev)
-    d_xs = torch.from_numpy(batch["xs"]).to(dev)
-    d_us = torch.from_numpy(batch["us"]).to(dev)
-    d_P = torch.from_numpy(batch["params"]).to(dev)
-    d_P_all = d_P.repeat(Q, 1, 1).contiguous()             # the queue's parameter tensor, resident: every step's batch has the same plan
+
+    # every step solves its OWN instances: timed step i of this rank = seed block rank*steps + i, warm-up steps = other blocks
+    def load_blocks(blocks):
+        seeds = np.concatenate([b * B + np.arange(B) for b in blocks])
+        h = workload.make_batch("srbd13", N, seeds)
+        return {k: torch.from_numpy(h[k]).to(dev).reshape((len(blocks), B) + h[k].shape[1:]) for k in ("x0", "xs", "us", "params")}
+
+    timed_blocks = [seed_block(rank, world, steps, warmup, "timed", i) for i in range(steps)]
+    warm_blocks = [seed_block(rank, world, steps, warmup, "warmup", i) for i in range(warmup)]
+    d_t = load_blocks(timed_blocks)
+    d_w = load_blocks(warm_blocks) if warmup else None
 
     def make_queue(order):
         e = DdpEngine("srbd13", N, Q * B, opts=dict(opts, waves_per_simd=wps, queue_order=order))
         e.use_torch_stream(torch.cuda.current_stream())
         e.enable_timing(True)
-        return e, FleetQueue(e, d_P_all, B, Q, collective=collective)
+        P_all = torch.zeros((Q * B, N + 1, npar), dtype=torch.float64, device=dev)      # the handle's parameter tensor, resident
+        return e, FleetQueue(e, P_all, B, Q, collective=collective)
 
     eng, fleet = make_queue(args.queue_order)
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)        # DDP iterations, rollouts over all launches (device-side sums)
 
     def barrier():
         if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(fl, n_steps):
-        for _ in range(n_steps):
-            fl.submit(d_x0, d_xs, d_us)                    # one step: one batch enters the queue (launch when the handle is full)
-        fl.flush()
+    def launch(fl, count):
+        n = fl.flush()                                         # ONE launch over the pending batches (+ async all-gather)
+        if count and n:
+            acc[0] += fl.si[:n, 10].sum()                      # sddp_stats.iters / .rollouts of the launch, summed on the stream
+            acc[1] += fl.si[:n, 13].sum()
 
-    def timed(fl, n_steps):
+    def run_steps(fl, d, n_steps, count=False):
+        for i in range(n_steps):
+            if fl.full:
+                launch(fl, count)
+            fl.submit(d["x0"][i], d["xs"][i], d["us"][i], d["params"][i])    # one step: one batch of new instances enters the queue
+        launch(fl, count)
+        fl.wait()                                              # every collective of the region has completed
+
+    def timed(fl, d, n_steps, count=False):
         barrier()
         t0 = time.perf_counter()
-        run_steps(fl, n_steps)
+        run_steps(fl, d, n_steps, count)
         barrier()
         return time.perf_counter() - t0
 
-    # warm-up: the W steps asked for, and at least one pass over every block of the handle the timed region will use, so that
-    # each of its instances has been solved once (code paths, caches, and the queue-order history)
-    priming = max(max(args.warmup, 0), min(Q, args.steps))
-    run_steps(fleet, priming)
+    # warm-up: W steps on instances the timed region never sees (code paths incl. the device-side stats sums, caches, clocks)
+    if warmup:
+        run_steps(fleet, d_w, warmup, count=True)
     barrier()
+    acc.zero_()
     eng.synchronize()
     eng.kernel_time_stats(reset=True)
+    acc += fleet.si[:1, 10].sum()                              # (first use of these device ops is never inside the timed region)
+    acc.zero_()
+    barrier()
     l0 = fleet.launches
-    elapsed = timed(fleet, args.steps)
+    elapsed = timed(fleet, d_t, steps, count=True)
     if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -210,64 +248,82 @@ def main():
     ksum, kcnt = eng.kernel_time_stats(reset=True)
     launches = fleet.launches - l0
     slots, last_grid, last_queued = eng.queue_info()
+    tot_iters, tot_roll = (int(v) for v in acc.tolist())
 
+    n_last = (steps - Q * ((steps - 1) // Q)) * B              # instances of the last launch: what the handle still holds
     x, u, st = eng.fetch()
-    st = st[:B]                                            # every block of the handle holds the same batch
-    iters, rollouts = st["iters"].astype(np.int64), st["rollouts"].astype(np.int64)
+    st = st[:n_last]
+    iters = st["iters"].astype(np.int64)
     kms = ksum / max(kcnt, 1)
-    abytes_batch = algorithmic_bytes(N, nx, nu, npar, iters, rollouts, B)
-    abytes_launch = abytes_batch * args.steps / max(launches, 1)          # average launch of the timed region
+    n_solves = steps * B
+    abytes_total = algorithmic_bytes(N, nx, nu, npar, np.array([tot_iters]), np.array([tot_roll]), n_solves)
+    abytes_launch = abytes_total / max(launches, 1)            # average launch of the timed region
     achieved = abytes_launch / (kms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(args.steps, Q) if (B == 1024 and N == 30 and world == 1) else (None, None)
+    traffic, traffic_src = pmc_traffic(steps, Q) if (B == 1024 and N == 30 and world == 1) else (None, None)
     out = {
-        "metric": "SRBD-DDP solves/sec (N=30, nx=13, nu=6)", "value": world * B * args.steps / elapsed, "unit": "solves/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "metric": "SRBD-DDP solves/sec (N=30, nx=13, nu=6)", "value": world * n_solves / elapsed, "unit": "solves/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"SRBD N={N} nx=13 nu=6, batch={B} independent MPC instances per GPU and step "
                                "(BASELINE configs[2]; x8 GPUs = configs[3]), cold start, whole line-search ladder "
-                               "(alpha=1..1e-12, 40 candidates) rolled out per iteration",
+                               "(alpha=1..1e-12, 40 candidates) rolled out per iteration; every step solves instances of its own "
+                               "(distinct seeds), none of them seen before the timed region",
                    "batch_per_gpu": B, "horizon_N": N, "solver_opts": opts, "algorithm": "MS-DDP, Gauss-Newton Hessians + exact torque term",
                    "queue_depth_steps": Q, "launches_timed": launches, "resident_slots": slots, "grid_last_launch": last_grid,
-                   "waves_per_simd": wps, "queue_order": "longest previous solve first" if args.queue_order else "index",
-                   "priming_steps": priming, "streams": 1,
-                   "collective": "all_gather(solution records) per launch" if collective else "none"},
-        "mean_iters": float(np.mean(iters)), "max_iters": int(np.max(iters)), "max_iters_hit_frac": float(np.mean(st["status"] == 1)),
-        "converged_frac": float(np.mean(st["converged"] == 1)), "line_search_stalled_frac": float(np.mean(st["status"] == 4)),
-        "mean_rollouts": float(np.mean(rollouts)),
-        "iterations_per_s": world * float(np.sum(iters)) * args.steps / elapsed,
+                   "waves_per_simd": wps, "queue_order": ORDER_NAMES[args.queue_order], "streams": 1,
+                   "seed_blocks": {"timed": [timed_blocks[0], timed_blocks[-1]], "warmup": ([warm_blocks[0], warm_blocks[-1]] if warmup else None),
+                                   "block": f"seeds b*{B} .. b*{B}+{B - 1}"},
+                   "collective": "asynchronous double-buffered all_gather(solution records) per launch, waited for inside the timed region"
+                                 if collective else "none",
+                   "gather_bytes_per_launch_per_rank": (fleet.gather_bytes // max(fleet.launches, 1)) if collective else 0},
+        "mean_iters": tot_iters / n_solves, "mean_rollouts": tot_roll / n_solves,
+        "last_launch": {"instances": int(n_last), "mean_iters": float(np.mean(iters)), "max_iters": int(np.max(iters)),
+                        "max_iters_hit_frac": float(np.mean(st["status"] == 1)), "converged_frac": float(np.mean(st["converged"] == 1)),
+                        "line_search_stalled_frac": float(np.mean(st["status"] == 4))},
+        "iterations_per_s": world * tot_iters / elapsed,
         # secondary: ~0.85 Mflop of fp64 per DDP iteration at (N, nx, nu) = (30, 13, 6) (dense backward
         # sweep 25.2 kflop/knot + model evaluation + one rollout), against the MI355X fp64 vector peak of 78.6 TFLOP/s
-        "fp64_algorithmic_tflops": world * float(np.sum(iters)) * args.steps / elapsed * 0.85e6 * (N / 30.0) / 1e12,
-        "fp64_vector_peak_frac": float(np.sum(iters)) * args.steps / elapsed * 0.85e6 * (N / 30.0) / 78.6e12,
+        "fp64_algorithmic_tflops": world * tot_iters / elapsed * 0.85e6 * (N / 30.0) / 1e12,
+        "fp64_vector_peak_frac": tot_iters / elapsed * 0.85e6 * (N / 30.0) / 78.6e12,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": ("solve_kernel_w2" if wps >= 2 else "solve_kernel") + "<SrbdModel<2,false>>", "kernel_ms": kms,
                      "launches": int(kcnt), "algorithmic_bytes_per_launch": abytes_launch,
-                     "note": "achieved = algorithmic bytes of the average timed launch (SURVEY 8(d) bytes per solve x the instances of "
-                             "the launch) / its HIP-event duration on the launch stream; one launch at a time on one stream; traffic is "
-                             "not measured in this run: it is read from the committed rocprofv3 PMC passes named in traffic_source"},
+                     "note": "achieved = algorithmic bytes of the average timed launch (SURVEY 8(d) bytes per solve, from the iteration "
+                             "and rollout counts of every instance of the timed region) / its HIP-event duration on the launch stream; "
+                             "one launch at a time on one stream; traffic is not measured in this run: it is read from the committed "
+                             "rocprofv3 PMC passes named in traffic_source"},
     }
     if rank == 0 and world == 1 and not args.no_extras:
-        n_x = min(args.steps, Q)
-        if args.queue_order:
-            # the same queue in plain index order (no history hint), over one full handle
-            e_ix, f_ix = make_queue(0)
-            run_steps(f_ix, n_x)
-            el = timed(f_ix, n_x)
-            out["index_order_solves_per_s"] = B * n_x / el
-            del f_ix, e_ix
+        n_x = min(steps, Q)
+        # the same instances in plain index order and (as a REPLAY: the handle has solved these very instances once before, so
+        # the history is exact foreknowledge -- what a fleet of recurring robots approaches, not a cold-start figure) longest
+        # previous solve first
+        for order, key in ((0, "index_order_solves_per_s"), (1, "replay_history_order_solves_per_s"), (2, "initial_cost_order_solves_per_s")):
+            if order == args.queue_order:
+                continue
+            e_o, f_o = make_queue(order)
+            run_steps(f_o, d_t if order == 1 else (d_w if warmup else d_t), n_x if order == 1 else min(max(warmup, 1), n_x))
+            out[key] = B * n_x / timed(f_o, d_t, n_x)
+            del f_o, e_o
         # strictly one batch per launch (the next step starts after the previous one's slowest instance has finished), the kernel
         # build with the full register file per instance: the latency of one batch
         e_lat = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
-        e_lat.use_torch_stream(torch.cuda.current_stream())
-        f_lat = FleetQueue(e_lat, d_P, B, 1)
-        n1 = min(args.steps, 6)
-        run_steps(f_lat, 1)
-        el1 = timed(f_lat, n1)
+        f_lat = FleetQueue(e_lat, torch.zeros((B, N + 1, npar), dtype=torch.float64, device=dev), B, 1)
+        n1 = min(steps, 6)
+        el1 = 0.0
+        for i in range(n1):
+            barrier()
+            t1 = time.perf_counter()
+            f_lat.submit(d_t["x0"][i], d_t["xs"][i], d_t["us"][i], d_t["params"][i])
+            f_lat.flush()
+            barrier()
+            el1 += time.perf_counter() - t1
         out["one_batch_in_flight_solves_per_s"] = B * n1 / el1
         out["one_batch_in_flight_ms_per_step"] = 1e3 * el1 / n1
         del f_lat, e_lat
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        batch = workload.make_batch("srbd13", N, np.arange(B))
         out.update(single_instance_extras(N, opts, workload, DdpEngine))
         out["ms_per_fleet_tick"] = fleet_tick(N, B, opts, workload, DdpEngine)
         # PCIe-inclusive batch rate (host-pointer C-ABI call: params in, x/u/stats out) -- reported, never `value`
@@ -289,40 +345,106 @@ def main():
         dist.destroy_process_group()
 
 
-def fleet_tick(N, B, opts, workload, DdpEngine, ticks=24):
+def sweep_flops_per_knot(nx, nu):
+    """SURVEY.md section 8(d), dense count of one backward-sweep knot incl. the DDP tensor terms"""
+    return (4 * nx ** 3 + 6 * nx ** 2 * nu + 2 * nu ** 2 * nx + (2 * nx ** 3 + 2 * nx ** 2 * nu + 2 * nx * nu ** 2) + nu ** 3 / 3
+            + 2 * nu ** 2 * (nx + 1) + 4 * nx ** 2 + 4 * nx * nu)
+
+
+def mw_batch(model, N, B, opts, workload, DdpEngine, reps=3):
+    """One cold-started batch of a reference-size model through the 4-wavefront kernel (solve_kernel_mw), device-resident
+    inputs, kernel time by HIP events on the launch stream: solves/s and the same roofline bookkeeping as the headline."""
+    from srbd_horizon_amd import _lib
+    nx, nu, npar = _lib.model_dims(model)
+    b = workload.make_batch(model, N, np.arange(B))
+    e = DdpEngine(model, N, B, opts=dict(opts, queue_order=2))
+    e.enable_timing(True)
+    wall = []
+    for _ in range(reps):
+        e.set_initial_state(b["x0"]); e.set_x_warmstart(b["xs"]); e.set_u_warmstart(b["us"])
+        e.set_params(b["params"]); e.synchronize()
+        e.kernel_time_stats(reset=True)
+        t1 = time.perf_counter()
+        e.solve_resident()
+        wall.append(time.perf_counter() - t1)
+    ksum, kcnt = e.kernel_time_stats(reset=True)
+    kms = ksum / max(kcnt, 1)
+    st = e.stats
+    iters, roll = st["iters"].astype(np.int64), st["rollouts"].astype(np.int64)
+    ab = algorithmic_bytes(N, nx, nu, npar, iters, roll, B)
+    flop_it = N * (sweep_flops_per_knot(nx, nu) + 2.0 * (nx * nu + nx * nx) + 6.0 * (nx + nu) ** 2)   # sweep + one rollout + model eval (approx.)
+    slots, grid, queued = e.queue_info()
+    return {"solves_per_s": B / min(wall), "kernel_solves_per_s": B / (kms * 1e-3), "batch": B, "horizon_N": N, "mean_iters": float(np.mean(iters)),
+            "max_iters": int(iters.max()), "mean_rollouts": float(np.mean(roll)), "converged_frac": float(np.mean(st["converged"] == 1)),
+            "slots": slots, "grid": grid, "kernel": f"solve_kernel_mw<{model}>", "kernel_ms": kms,
+            "algorithmic_bytes": ab, "achieved_gbs": ab / (kms * 1e-3) / 1e9, "hbm_frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "fp64_algorithmic_tflops": float(iters.sum()) * flop_it / (kms * 1e-3) / 1e12,
+            "fp64_vector_peak_frac": float(iters.sum()) * flop_it / (kms * 1e-3) / 78.6e12,
+            "note": f"{model} N={N} cold start, one launch of {B} instances (queue on {grid} slots of 4 wavefronts, largest initial cost "
+                    "first); solves_per_s includes the host-pointer result fetch, kernel_* is the HIP-event kernel time"}
+
+
+def fleet_tick(N, B, opts, workload, DdpEngine, ticks=100, budget=6, cpu_ticks=6):
     """ms / MPC tick of a FLEET: B robots, each warm-started from its previous solution advanced by one knot (sddp_advance), one
     sddp_solve_resident per tick (results fetched to the host every tick), against the C port on the host threads for the same
-    sequence of problems.  The per-robot figure (`ms_per_mpc_tick`, B = 1) is one wavefront of the chip; this is the chip."""
+    sequence of problems.  The per-robot figure (`ms_per_mpc_tick`, B = 1) is one wavefront of the chip; this is the chip.
+    Run twice: to convergence (a tick lasts as long as its slowest robot: the tail), and with the real-time remedy of MPC -- at
+    most `budget` DDP iterations per tick, an unfinished iterate (status 1) simply carried on as the next tick's warm start."""
     from oracle import cport, ddp as oddp, models as omodels
     b = workload.make_batch("srbd13", N, np.arange(B))
-    e = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
-    e.set_initial_state(b["x0"]); e.set_x_warmstart(b["xs"]); e.set_u_warmstart(b["us"])
-    e.set_params(b["params"])
-    x, u = e.solve_resident()                                  # cold solve: every robot's first tick
-    P = b["params"].copy()
     cst, o = omodels.RobotConsts(), oddp.DdpOptions(**opts)
     threads = max(1, min(16, os.cpu_count() or 1))
-    gms, cms, its, same = [], [], [], []
-    for t in range(ticks):
-        p_last, x0 = P[:, -1].copy(), x[:, 1].copy()          # the plan's last column repeats; the robot is where the plan said
-        xs_ws = np.concatenate([x[:, 1:], x[:, -1:]], axis=1); xs_ws[:, 0] = x0
-        us_ws = np.concatenate([u[:, 1:], u[:, -1:]], axis=1)
-        P = np.concatenate([P[:, 1:], p_last[:, None]], axis=1)
-        t1 = time.perf_counter()
-        e.advance(p_last, x0)
-        x, u = e.solve_resident()
-        gms.append(1e3 * (time.perf_counter() - t1))
-        its.append(float(e.stats["iters"].mean()))
-        if t >= ticks - 6:                                     # CPU: the last ticks only (bounded sample)
+
+    def run(max_iters, with_cpu):
+        e = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
+        e.set_initial_state(b["x0"]); e.set_x_warmstart(b["xs"]); e.set_u_warmstart(b["us"])
+        e.set_params(b["params"])
+        x, u = e.solve_resident()                              # cold solve: every robot's first tick (to convergence in both runs)
+        if max_iters is not None:
+            e.set_options(max_iters=max_iters)
+        P = b["params"].copy()
+        gms, cms, same, imean, imax, i99, unfinished, cost = [], [], [], [], [], [], [], []
+        for t in range(ticks):
+            p_last, x0 = P[:, -1].copy(), x[:, 1].copy()      # the plan's last column repeats; the robot is where the plan said
+            xs_ws = np.concatenate([x[:, 1:], x[:, -1:]], axis=1); xs_ws[:, 0] = x0
+            us_ws = np.concatenate([u[:, 1:], u[:, -1:]], axis=1)
+            P = np.concatenate([P[:, 1:], p_last[:, None]], axis=1)
             t1 = time.perf_counter()
-            _, _, st = cport.solve_batch(cst, o, x0, P, xs_ws, us_ws, threads=threads)
-            cms.append(1e3 * (time.perf_counter() - t1))
-            same.append(float(np.mean(st[:, 1].astype(int) == e.stats["iters"])))
-    return {"batch": B, "gpu_ms_per_tick_median": float(np.median(gms[4:])), "gpu_ms_per_tick_p99": float(np.percentile(gms[4:], 99)),
-            "mean_iters": float(np.mean(its[4:])), "cpu_ms_per_tick_median": float(np.median(cms)), "cpu_threads": threads,
-            "same_iters_as_gpu_frac": float(np.mean(same)),
+            e.advance(p_last, x0)
+            x, u = e.solve_resident()
+            gms.append(1e3 * (time.perf_counter() - t1))
+            it = e.stats["iters"]
+            imean.append(float(it.mean())); imax.append(int(it.max())); i99.append(float(np.percentile(it, 99)))
+            unfinished.append(float(np.mean(e.stats["status"] == 1)))
+            cost.append(float(e.stats["cost"].mean()))
+            if with_cpu and t >= ticks - cpu_ticks:            # CPU: the last ticks only (bounded sample)
+                t1 = time.perf_counter()
+                _, _, st = cport.solve_batch(cst, o, x0, P, xs_ws, us_ws, threads=threads)
+                cms.append(1e3 * (time.perf_counter() - t1))
+                same.append(float(np.mean(st[:, 1].astype(int) == it)))
+        return dict(gms=np.array(gms[4:]), cms=cms, same=same, imean=imean[4:], imax=np.array(imax[4:]), i99=i99[4:],
+                    unfinished=unfinished[4:], cost=np.array(cost[4:]))
+
+    full, bud = run(None, True), run(budget, False)
+    worst = np.argsort(-full["gms"])[:5]
+    return {"batch": B, "ticks": ticks - 4,
+            "gpu_ms_per_tick_median": float(np.median(full["gms"])), "gpu_ms_per_tick_p99": float(np.percentile(full["gms"], 99)),
+            "gpu_ms_per_tick_max": float(full["gms"].max()),
+            "mean_iters": float(np.mean(full["imean"])), "iters_p99": float(np.mean(full["i99"])), "iters_max_per_tick_median": float(np.median(full["imax"])),
+            "iters_max": int(full["imax"].max()),
+            "slowest_ticks": [{"tick": int(i) + 4, "ms": float(full["gms"][i]), "max_iters_of_a_robot": int(full["imax"][i])} for i in worst],
+            "deadline_10ms_miss_frac": float(np.mean(full["gms"] > 10.0)),
+            "budgeted": {"max_iters_per_tick": budget, "ms_per_tick_median": float(np.median(bud["gms"])),
+                         "budgeted_p99_ms": float(np.percentile(bud["gms"], 99)), "ms_per_tick_max": float(bud["gms"].max()),
+                         "deadline_10ms_miss_frac": float(np.mean(bud["gms"] > 10.0)),
+                         "unfinished_robots_per_tick_mean": float(np.mean(bud["unfinished"])),
+                         "mean_cost_ratio_to_converged": float(np.mean(bud["cost"] / full["cost"]))},
+            "cpu_ms_per_tick_median": float(np.median(full["cms"])), "cpu_threads": threads,
+            "same_iters_as_gpu_frac": float(np.mean(full["same"])),
             "note": "srbd13 N=30, every robot warm-started from its previous solution advanced by one knot; GPU tick = sddp_advance + "
-                    "sddp_solve_resident incl. the PCIe copies of p_last / x0 in and x / u / stats out; CPU = the C port, OpenMP over robots"}
+                    "sddp_solve_resident incl. the PCIe copies of p_last / x0 in and x / u / stats out; CPU = the C port, OpenMP over robots; "
+                    "a tick to convergence ends with its slowest robot (slowest_ticks: its iteration count), the budgeted run caps "
+                    "every robot at max_iters_per_tick and carries unfinished iterates over"}
 
 
 def single_instance_extras(N, opts, workload, DdpEngine):
@@ -380,21 +502,10 @@ def single_instance_extras(N, opts, workload, DdpEngine):
             "median": float(np.median(tms[10:])), "p99": float(np.percentile(tms[10:], 99)),
             "solve_median": float(np.median(lp.solve_ms[10:])), "mean_iters": float(np.mean(its[10:])),
             "cpu": cpu_tick_baseline(mname, traced(mname, ns, nt)[10:], its[10:])}
-    # BASELINE configs[4] as a batch: srbd37, N = 60, multiple shooting from a cold start with open defects, one launch
-    # (4 wavefronts per instance, one instance per CU resident: 256 slots, the rest queue)
-    B5 = 512
-    b5 = workload.make_batch("srbd37", 60, np.arange(B5))
-    e5 = DdpEngine("srbd37", 60, B5, opts=opts)
-    t5 = []
-    for _ in range(3):
-        e5.set_initial_state(b5["x0"]); e5.set_x_warmstart(b5["xs"]); e5.set_u_warmstart(b5["us"])
-        e5.set_params(b5["params"]); e5.synchronize()
-        t1 = time.perf_counter()
-        e5.solve_resident()
-        t5.append(time.perf_counter() - t1)
-    out["srbd37_n60_batch"] = {"solves_per_s": B5 / min(t5), "batch": B5, "mean_iters": float(np.mean(e5.stats["iters"])),
-                               "converged_frac": float(np.mean(e5.stats["converged"] == 1)), "slots": e5.queue_info()[0],
-                               "note": "configs[4]: srbd37 N=60 cold start, host-pointer result fetch included"}
+    # the 4-wavefront kernel as a batch: BASELINE configs[4] (srbd37, N = 60) and the reference's own problem (srbd37, ns = 20,
+    # dsrbd_example.py:30-31), cold start with open defects, one launch (one instance per CU resident, the rest queue)
+    out["srbd37_n60_batch"] = mw_batch("srbd37", 60, 512, opts, workload, DdpEngine)
+    out["srbd37_n20_batch"] = mw_batch("srbd37", 20, 1024, opts, workload, DdpEngine)
     return out
 
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDDP_ABI_VERSION 5
+#define SDDP_ABI_VERSION 6
 
 /* model ids */
 #define SDDP_MODEL_SRBD13 0 /* nx=13 nu=6  np=19 : BASELINE.json metric model (contacts are per-knot parameters) */
@@ -59,10 +59,17 @@ typedef struct sddp_options {
                                            one-wavefront-per-instance kernel (srbd13) has both builds. */
     int    queue_order;                 /* scheduling hint, no effect on results.  A solve launch runs on the workgroups that are
                                            resident on the device at once ("slots": 256 CUs x 4 SIMDs x waves_per_simd for srbd13);
-                                           a batch with more instances than slots is a work queue the slots pull from.  1 (default):
-                                           the queue is ordered by the iteration count of each instance's PREVIOUS solve on this
-                                           handle, longest first (never-solved first): a launch ends with its slowest instance, so
-                                           the slow ones start first.  0: index order. */
+                                           a batch with more instances than slots is a work queue the slots pull from.  A launch ends
+                                           with its slowest instance, so the slow ones should start first:
+                                           1 (default): longest PREVIOUS solve first -- the queue is ordered by the iteration count of
+                                              each instance's previous solve on this handle (never-solved first): the predictor of a
+                                              fleet whose robots recur tick after tick;
+                                           2: largest INITIAL COST first -- a pre-pass of the same launch evaluates the total cost of
+                                              every instance's warm start and the queue is sorted by it (descending): needs no history,
+                                              the order for cold queues (instances never seen before);
+                                           0: index order. */
+    int    max_slots;                   /* 0 (default): every workgroup the device can keep resident is a queue slot.  > 0: at most
+                                           this many (diagnostics and tests: a queue on few instances); reported by sddp_queue_info */
 } sddp_options;
 
 /* replaces what the reference bakes into the CasADi graphs from the URDF and the rosparam server
@@ -98,8 +105,11 @@ typedef struct sddp_stats {
     double expected;   /* last expected reduction -(dV1+dV2)                */
     int    iters;      /* accepted iterations                               */
     int    converged;  /* 1/0                                               */
-    int    status;     /* 0 ok, 1 max_iters, 2 regularisation overflow, 3 non-finite, 4 line search exhausted with the
-                          optimality conditions not met (converged = 0) */
+    int    status;     /* 0 ok (converged = 1), 1 max_iters, 2 regularisation overflow, 3 non-finite cost, 4 line search
+                          exhausted with the optimality conditions not met (converged = 0).  An exhausted line search (no step
+                          length >= alpha_converge_threshold decreases the merit function) counts as converged -- status 0 -- only
+                          with closed gaps (gap <= gap_tol) and expected <= cost_reduction_ths * max(1, |cost|): a RELATIVE test,
+                          where the regular exits test expected / |dJ| < cost_reduction_ths absolutely */
     int    rollouts;   /* forward passes executed                           */
 } sddp_stats;
 
@@ -146,8 +156,12 @@ int  sddp_solve_range_device(sddp_handle* h, const double* d_params, int first, 
 int  sddp_queue_info(sddp_handle* h, int* slots, int* last_grid, int* last_queued);
 /* results of the last device solve (x, u, stats of the whole batch) to host pointers; waits for the stream */
 int  sddp_fetch(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats /*[B] or NULL*/);
-/* which: 0 xs [B][N+1][nx], 1 us [B][N][nu], 2 stats [B] (sddp_stats), 3 gains [slots][N][nu*(nx+1)] (per slot: instance b's
- * gains only while B <= slots), 4 x0 [B][nx], 5 params [B][N+1][np] (the resident tensor of sddp_set_params) */
+/* which: 0 xs [B][N+1][nx], 1 us [B][N][nu], 2 stats [B] (sddp_stats), 3 gains [slots][N][nu*(nx+1)], 4 x0 [B][nx],
+ * 5 params [B][N+1][np] (the resident tensor of sddp_set_params), 6 order [last_queued] (int: the instance indices in the
+ * order the last queued launch handed them out; queue_order 1 or 2 only).  The feedback gains (3) are work buffers of the queue SLOTS:
+ * row b holds instance b's gains (kff then K row-major, of its last backward sweep) only after a launch that covered the
+ * instances from 0 without a queue (sddp_solve / sddp_solve_device / sddp_solve_resident with B <= slots, or a range with
+ * first = 0 and count <= slots); after any other launch the call returns SDDP_ERR_ARG instead of another robot's gains. */
 int  sddp_device_ptr(sddp_handle* h, int which, void** ptr, long long* bytes);
 /* average device time (ms) of the last `sddp_solve*` kernel launch measured with HIP events on the handle's stream */
 int  sddp_last_kernel_ms(sddp_handle* h, double* ms);

@@ -198,9 +198,9 @@ def solve(model, x0, P, xs_ws, us_ws, opt: DdpOptions | None = None) -> DdpResul
                 continue
             # alpha fell below alpha_converge_threshold (App. C: "stop").  No step length decreases the merit function any
             # more; that is an optimum only if the multiple-shooting gaps are closed and the model predicts (next to) no
-            # decrease either: expected <= cost_reduction_ths relative to the cost.  Otherwise: stalled, status 4.
-            status = 4
+            # decrease either: expected <= cost_reduction_ths RELATIVE to the cost (status 0).  Otherwise: stalled, status 4.
             converged = bool(gap <= opt.gap_tol and expected <= opt.cost_reduction_ths * max(1.0, abs(J)))
+            status = 0 if converged else 4
             alpha = 0.0
             break
         alpha = a

@@ -25,7 +25,8 @@ class SddpOptions(C.Structure):
     _fields_ = [("max_iters", C.c_int), ("alpha_0", C.c_double), ("alpha_converge_threshold", C.c_double),
                 ("line_search_decrease_factor", C.c_double), ("beta", C.c_double), ("cost_reduction_ths", C.c_double),
                 ("mu0", C.c_double), ("initial_rollout", C.c_int), ("gap_tol", C.c_double), ("mu_min", C.c_double),
-                ("mu_max", C.c_double), ("second_order", C.c_int), ("waves_per_simd", C.c_int), ("queue_order", C.c_int)]
+                ("mu_max", C.c_double), ("second_order", C.c_int), ("waves_per_simd", C.c_int), ("queue_order", C.c_int),
+                ("max_slots", C.c_int)]
 
 
 class SddpModelConsts(C.Structure):
@@ -96,13 +97,14 @@ _lib = None
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/sddp_api.hip for gfx950 into libsddp_hip.so (in-tree, so it travels to the GPU box)."""
     src = os.path.join(CSRC, "sddp_api.hip")
-    deps = [src, os.path.join(CSRC, "sddp_kernels.hpp"), os.path.join(CSRC, "sddp_kernels_mw.hpp"), os.path.join(CSRC, "sddp_models.hpp"),
-            os.path.join(INCLUDE, "sddp.h")]
+    sort_src = os.path.join(CSRC, "sddp_sort.hip")
+    deps = [src, sort_src, os.path.join(CSRC, "sddp_kernels.hpp"), os.path.join(CSRC, "sddp_kernels_mw.hpp"), os.path.join(CSRC, "sddp_models.hpp"),
+            os.path.join(CSRC, "sddp_sort.hpp"), os.path.join(INCLUDE, "sddp.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, "-I" + CSRC,
-           src, "-o", LIB_PATH]
+           src, sort_src, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -129,7 +131,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.sddp_abi_version() != 5:
+    if lib.sddp_abi_version() != 6:
         raise RuntimeError("libsddp_hip.so ABI version mismatch")
     _lib = lib
     return lib

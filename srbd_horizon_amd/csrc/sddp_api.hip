@@ -15,6 +15,7 @@
 #include "sddp_kernels.hpp"
 #include "sddp_kernels_mw.hpp"
 #include "sddp_models.hpp"
+#include "sddp_sort.hpp"
 
 using namespace sddp;
 
@@ -74,6 +75,12 @@ struct sddp_handle {
     int* qhead = nullptr;           // device queue head
     int* order = nullptr;           // [B] queue order of the next launch
     int* hist = nullptr;            // [B] iterations of each instance's previous solve (-1: none)
+    // cold-queue order (queue_order = 2): initial-cost keys of the launch, their sorted copy, the unsorted index list, sort scratch
+    double *qkey = nullptr, *qkey2 = nullptr;
+    int* order_in = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    bool gains_by_instance = false; // the last solve launch ran instance b on slot b (no queue, first = 0): sddp_device_ptr(3)
     struct KInfo { const void* fn = nullptr; int slots = 0; };
     KInfo kinfo[2];                 // per kernel build: dynamic-LDS attribute set, resident workgroups on this device
     int last_grid = 0, last_queued = 0;
@@ -151,12 +158,10 @@ int kernel_slots(sddp_handle* h, KernelFn kern, int* slots) {
     int per_cu = 0;
     HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
     if (!MW) per_cu = std::min(per_cu, 4 * (h->opts.waves_per_simd >= 2 ? 2 : 1));   // the two builds: 1 or 2 wavefronts per SIMD
-    if (const char* e = std::getenv("SDDP_SLOTS_PER_CU")) per_cu = std::atoi(e);     // diagnostic override
     per_cu = std::max(1, std::min(per_cu, 32));
     auto& k = h->kinfo[h->kinfo[0].fn ? 1 : 0];
     k.fn = reinterpret_cast<const void*>(kern);
     k.slots = per_cu * std::max(1, h->cus);
-    if (const char* e = std::getenv("SDDP_MAX_SLOTS")) k.slots = std::max(1, std::min(k.slots, std::atoi(e)));   // tests: a queue on few instances
     *slots = k.slots;
     return SDDP_OK;
 }
@@ -172,18 +177,33 @@ int launch_solve(sddp_handle* h, SolveArgs a, int first, int count) {
     int slots = 0;
     int rc = kernel_slots<M>(h, kern, &slots);
     if (rc != SDDP_OK) return rc;
-    const int grid = std::min(count, std::min(slots, h->wslots));
+    int grid = std::min(count, std::min(slots, h->wslots));
+    if (h->opts.max_slots > 0) grid = std::min(grid, h->opts.max_slots);
     a.first = first; a.count = count;
     if (count > grid) {
         HIP_TRY(h, hipMemsetAsync(h->qhead, 0, sizeof(int), h->stream));
         a.qhead = h->qhead;
-        if (h->opts.queue_order) {
+        if (h->opts.queue_order == 1) {            // longest previous solve first
             hipLaunchKernelGGL(queue_order_kernel, dim3(1), dim3(1024), 0, h->stream, first, count, h->hist, h->order);
             HIP_TRY(h, hipGetLastError());
+            a.order = h->order;
+        } else if (h->opts.queue_order == 2) {     // largest initial cost first: keys by a pre-pass over the launch's instances
+            if (!h->qkey) {
+                HIP_TRY(h, hipMalloc((void**)&h->qkey, size_t(h->B) * sizeof(double)));
+                HIP_TRY(h, hipMalloc((void**)&h->qkey2, size_t(h->B) * sizeof(double)));
+                HIP_TRY(h, hipMalloc((void**)&h->order_in, size_t(h->B) * sizeof(int)));
+                HIP_TRY(h, sort_pairs_desc_temp_bytes(h->B, &h->sort_tmp_bytes));
+                HIP_TRY(h, hipMalloc(&h->sort_tmp, std::max<size_t>(h->sort_tmp_bytes, 16)));
+            }
+            hipLaunchKernelGGL(queue_cost_key_kernel<M>, dim3(count), dim3(kWave), 0, h->stream, a.c, a.N, first, count, a.x0, a.P, a.xs,
+                               a.us, h->qkey, h->order_in);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, sort_pairs_desc(h->sort_tmp, h->sort_tmp_bytes, h->qkey, h->qkey2, h->order_in, h->order, count, h->stream));
             a.order = h->order;
         }
     }
     h->last_grid = grid; h->last_queued = count > grid ? count : 0;
+    h->gains_by_instance = (count <= grid && first == 0);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         while (h->ev.size() < 2 * (h->pending + 1)) {
@@ -283,7 +303,8 @@ int validate_options(sddp_handle* h, const sddp_options& o) {
         std::log(o.alpha_converge_threshold / o.alpha_0) / std::log(o.line_search_decrease_factor) > 4096.0)
         return fail(h, SDDP_ERR_ARG, "line search ladder longer than 4096 step lengths (line_search_decrease_factor too close to 1 "
                                      "or alpha_converge_threshold too small)");
-    if (o.queue_order != 0 && o.queue_order != 1) return fail(h, SDDP_ERR_ARG, "queue_order must be 0 or 1");
+    if (o.queue_order < 0 || o.queue_order > 2) return fail(h, SDDP_ERR_ARG, "queue_order must be 0, 1 or 2");
+    if (o.max_slots < 0) return fail(h, SDDP_ERR_ARG, "max_slots must be >= 0");
     if (o.second_order < 0 || o.second_order > 2) return fail(h, SDDP_ERR_ARG, "second_order must be 0, 1 or 2");
     return SDDP_OK;
 }
@@ -319,6 +340,7 @@ void sddp_default_options(sddp_options* o) {
     o->second_order = 1;
     o->waves_per_simd = 1;
     o->queue_order = 1;
+    o->max_slots = 0;
 }
 
 void sddp_default_consts(sddp_model_consts* c) {
@@ -379,6 +401,7 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     DISPATCH(h, max_slots, h, &slots);
     if (rc != SDDP_OK) { g_create_error = h->err; delete h; return rc; }
     h->wslots = std::min(batch, slots);
+    if (h->opts.max_slots > 0) h->wslots = std::min(h->wslots, h->opts.max_slots);
     const size_t W = size_t(h->wslots);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     h->own_stream = (e == hipSuccess);
@@ -422,7 +445,7 @@ void sddp_destroy(sddp_handle* h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->xc, h->uc, h->tick_in, h->step_buf, h->dft, h->gains, h->rec, h->scal, h->stats,
-                    h->qhead, h->order, h->hist};
+                    h->qhead, h->order, h->hist, h->qkey, h->qkey2, h->order_in, h->sort_tmp};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->pinned) (void)hipHostFree(h->pinned);
@@ -722,9 +745,16 @@ int sddp_device_ptr(sddp_handle* h, int which, void** ptr, long long* bytes) {
         case 0: *ptr = h->xs; n = (long long)(h->n_x() * sizeof(double)); break;
         case 1: *ptr = h->us; n = (long long)(h->n_u() * sizeof(double)); break;
         case 2: *ptr = h->stats; n = (long long)(size_t(h->B) * sizeof(sddp_stats)); break;
-        case 3: *ptr = h->gains; n = (long long)(size_t(h->wslots) * h->N * h->d.nu * (h->d.nx + 1) * sizeof(double)); break;   // per slot
+        case 3:   // per slot: row b is instance b's only after a launch without a queue that started at instance 0
+            if (!h->gains_by_instance)
+                return fail(h, SDDP_ERR_ARG, "the gains are per queue slot: the last solve launch was queued or did not start at instance 0, "
+                                             "so row b is not instance b's (solve with B <= slots, sddp_queue_info)");
+            *ptr = h->gains; n = (long long)(size_t(h->wslots) * h->N * h->d.nu * (h->d.nx + 1) * sizeof(double)); break;
         case 4: *ptr = h->x0; n = (long long)(size_t(h->B) * h->d.nx * sizeof(double)); break;
         case 5: *ptr = h->P; n = (long long)(h->n_p() * sizeof(double)); break;
+        case 6:   // the order the last queued launch handed its instances out in (absolute instance indices)
+            if (!h->last_queued || h->opts.queue_order == 0) return fail(h, SDDP_ERR_ARG, "the last solve launch had no ordered queue");
+            *ptr = h->order; n = (long long)(size_t(h->last_queued) * sizeof(int)); break;
         default: return fail(h, SDDP_ERR_ARG, "unknown buffer id");
     }
     if (bytes) *bytes = n;
@@ -813,6 +843,7 @@ int sddp_backward(sddp_handle* h, const double* params, double mu, double* gains
     a.mu = mu;
     DISPATCH(h, launch_backward, h, a);
     if (rc != SDDP_OK) return rc;
+    h->gains_by_instance = true;
     if (gains_out) HIP_TRY(h, hipMemcpyAsync(gains_out, h->gains, h->n_g() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (scal_out) {

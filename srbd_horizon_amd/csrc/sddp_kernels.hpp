@@ -829,8 +829,9 @@ __device__ __forceinline__ void solve_instance(const SolveArgs& A, double* s, co
                 if (theta != 0.0) { theta = 0.0; continue; }                       // redo with the plain Gauss-Newton step
                 // alpha fell below alpha_converge_threshold: stop.  An optimum only with closed gaps and (next to) no predicted
                 // decrease either; otherwise the line search has stalled (status 4, not converged)
-                alpha = 0.0; status = 4; stop = true;
+                alpha = 0.0; stop = true;
                 converged = (gap <= o.gap_tol && expected <= o.cost_reduction_ths * fmax(1.0, fabs(J))) ? 1 : 0;
+                status = converged ? 0 : 4;
                 break;
             } while (true);
             if (stop) break;
@@ -933,6 +934,44 @@ __global__ __launch_bounds__(1024) void queue_order_kernel(int first, int count,
         const int h = hist[first + i];
         const int pos = atomicAdd(&bins[h < 0 ? kOrderBins - 1 : (h > 256 ? 256 : h)], 1);
         order[pos] = first + i;
+    }
+}
+
+// Queue order for a COLD queue (sddp_options.queue_order = 2): the key of an instance is the total cost of its warm start
+// (x_0 := x0 as the solve does; multiple-shooting cost of the given xs / us), evaluated here by one wavefront per instance, one
+// lane per knot -- the same model code and the same sum the solve itself starts from.  The keys are then sorted in descending
+// order (sddp_sort.hip): the instances farthest from their optimum start first.  Nothing here depends on an earlier solve.
+template <class M>
+__global__ __launch_bounds__(kWave) void queue_cost_key_kernel(DevConsts c, int N, int first, int count, const double* __restrict__ x0,
+                                                               const double* __restrict__ P, const double* __restrict__ xs,
+                                                               const double* __restrict__ us, double* __restrict__ key,
+                                                               int* __restrict__ idx) {
+    constexpr int NX = M::NX, NU = M::NU, NP = M::NP;
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= count) return;
+    const int b = first + i;
+    const double* xb = xs + size_t(b) * (N + 1) * NX;
+    const double* ub = us + size_t(b) * N * NU;
+    const double* Pb = P + size_t(b) * (N + 1) * NP;
+    double Jl = 0.0;
+    for (int k = lane; k <= N; k += kWave) {
+        double x[NX];
+        const double* xk = k == 0 ? x0 + size_t(b) * NX : xb + k * NX;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) x[j] = xk[j];
+        if (k < N) {
+            double u[NU], xn[NX];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) u[j] = ub[k * NU + j];
+            Jl += M::step(c, x, u, Pb + k * NP, k, xn);
+        } else {
+            Jl += M::term_cost(c, x, Pb + k * NP);
+        }
+    }
+    const double J = wave_sum(Jl);
+    if (lane == 0) {
+        key[i] = (J == J) ? J : __builtin_huge_val();      // a non-finite start sorts first (it ends at once with status 3)
+        idx[i] = b;
     }
 }
 

@@ -759,8 +759,9 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
             } while (true);
             if (stop) break;
             if (!accepted) {   // alpha below the threshold: stop; converged only with closed gaps and no predicted decrease (status 4)
-                alpha = 0.0; status = 4;
+                alpha = 0.0;
                 converged = (gap <= o.gap_tol && expected <= o.cost_reduction_ths * fmax(1.0, fabs(J))) ? 1 : 0;
+                status = converged ? 0 : 4;
                 break;
             }
             alpha = a_win;
@@ -803,19 +804,23 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
 template <class M>
 __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double s[];
-    __shared__ int q_pos;
+    // the queue position lives in a control word of the dynamic LDS block (CTL + 15), so that the occupancy query and the
+    // dynamic-LDS attribute cover every byte of LDS the kernel uses
+    int* q_pos = reinterpret_cast<int*>(s + LdsMW<M>::CTL + 15);
     const int slot = blockIdx.x;
     const bool queued = A.qhead != nullptr;
-    if (queued && threadIdx.x == 0) q_pos = atomicAdd(A.qhead, 1);
+    if (queued && threadIdx.x == 0) *q_pos = atomicAdd(A.qhead, 1);
     __syncthreads();
-    int i = queued ? q_pos : slot;
+    int i = queued ? *q_pos : slot;
+    __syncthreads();                                   // every thread has read it before the solve re-zeroes the LDS block
     while (i < A.count) {
         const int b = (queued && A.order) ? A.order[i] : A.first + i;
         solve_instance_mw<M>(A, s, b, slot);           // ends with a barrier: q_pos may be rewritten
         if (!queued) break;
-        if (threadIdx.x == 0) q_pos = atomicAdd(A.qhead, 1);
+        if (threadIdx.x == 0) *q_pos = atomicAdd(A.qhead, 1);
         __syncthreads();
-        i = q_pos;
+        i = *q_pos;
+        __syncthreads();
     }
 }
 

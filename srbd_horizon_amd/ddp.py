@@ -25,7 +25,7 @@ from .problem import Problem
 # option keys the reference forwards to pyddp.DdpSolverOptions (ddp.py:16-35) + engine extras
 _REFERENCE_KEYS = ("max_iters", "alpha_0", "alpha_converge_threshold", "line_search_decrease_factor", "beta",
                    "cost_reduction_ths", "mu0")
-_EXTRA_KEYS = ("initial_rollout", "gap_tol", "mu_min", "mu_max", "second_order", "waves_per_simd", "queue_order")
+_EXTRA_KEYS = ("initial_rollout", "gap_tol", "mu_min", "mu_max", "second_order", "waves_per_simd", "queue_order", "max_slots")
 
 # What each registered analytic model implements, by the reference's function names (prb.py:166-204, :379-402):
 #   cost:  name -> (model constant that carries its gain or None, "state" = nodes 1..ns | "stage" = nodes 0..ns-1)

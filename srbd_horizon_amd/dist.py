@@ -33,6 +33,17 @@ def pack_records(x, u, cost, iters):
                       iters.reshape(B, 1).to(torch.float64)], dim=1).contiguous()
 
 
+def pack_records_into(out, x, u, cost, iters):
+    """pack_records into a preallocated [B, words] torch tensor (no allocation: the fleet queue's pack buffers); -> out"""
+    B = x.shape[0]
+    nxw, nuw = x.shape[1] * x.shape[2], u.shape[1] * u.shape[2]
+    out[:, :nxw].copy_(x.reshape(B, nxw))
+    out[:, nxw:nxw + nuw].copy_(u.reshape(B, nuw))
+    out[:, nxw + nuw].copy_(cost)
+    out[:, nxw + nuw + 1].copy_(iters)             # int32 -> float64
+    return out
+
+
 def unpack_records(rec, N: int, nx: int, nu: int):
     B = rec.shape[0]
     nxw, nuw = (N + 1) * nx, N * nu

@@ -219,6 +219,17 @@ class DdpEngine:
         """One asynchronous launch over the instances [first, first + count); `params` is the whole [B, N+1, np] tensor."""
         self._chk(self.lib.sddp_solve_range_device(self.h, self._dev(params, (self.B, self.N + 1, self.np_)), int(first), int(count)))
 
+    def last_queue_order(self):
+        """Instance indices in the order the last queued launch handed them out (queue_order 1 or 2); waits for the stream."""
+        import torch
+        self.synchronize()
+        ptr, nbytes = self.device_buffer(6)
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+        return torch.as_tensor(_Dev(), device=torch.device("cuda", torch.cuda.current_device())).cpu().numpy().copy()
+
     def queue_info(self):
         """(slots the work buffers exist for, grid of the last launch, queue length of the last launch or 0)."""
         a, b, c = C.c_int(), C.c_int(), C.c_int()

@@ -33,3 +33,17 @@ def test_bench_defaults_and_contract_fields():
     assert bench.HBM_PEAK_GBS == 8000.0
     assert "GPU_MAX_HW_QUEUES" not in src                            # one stream, one launch at a time: no hardware-queue tuning
     assert "traffic_source" in src                                   # the PMC figure is labelled as read from profiles/, not measured live
+
+
+def test_no_timed_instance_is_solved_before_the_timed_region():
+    """every step solves instances of its own; the warm-up blocks are disjoint from every rank's timed blocks,
+    ranks do not share blocks, and the shipped default is the history-free queue order."""
+    for world, steps, warmup in ((1, 20, 5), (8, 20, 5), (2, 96, 16), (1, 1, 0), (4, 3, 7)):
+        timed = [bench.seed_block(r, world, steps, warmup, "timed", i) for r in range(world) for i in range(steps)]
+        warm = [bench.seed_block(r, world, steps, warmup, "warmup", i) for r in range(world) for i in range(warmup)]
+        assert len(set(timed)) == world * steps and len(set(warm)) == world * warmup
+        assert not set(timed) & set(warm)
+        assert sorted(timed) == list(range(world * steps))            # rank r owns the contiguous blocks r*steps .. r*steps+steps-1
+    src = open(bench.__file__).read()
+    assert '"--queue-order", type=int, default=2' in src              # `value` = largest initial cost first: no history
+    assert "replay_history_order_solves_per_s" in src                 # the foreknowledge figure is an extra, named as a replay

@@ -1,5 +1,5 @@
-"""bench.py's N > 1 step on CPU: the SAME `fleet.FleetQueue` (submit -> flush = one launch + pack_records + all-gather) at
-world size 2 with gloo.  The HIP engine is GPU-only, so each rank's engine is a stand-in with the engine's three methods that
+"""bench.py's N > 1 step on CPU: the SAME `fleet.FleetQueue` (submit -> flush = one launch + record packing + asynchronous,
+double-buffered all-gather) at world size 2 with gloo, over three launches of distinct instances.  The HIP engine is GPU-only, so each rank's engine is a stand-in with the engine's three methods that
 solves its shard with the plain-C oracle; what is tested is sharding by rank (bench.py's seeds), the flush bookkeeping, record
 packing from the engine's stats views, the collective, and that the gathered records equal an unsharded solve."""
 import os
@@ -58,25 +58,42 @@ def _free_port():
     return p
 
 
+def _seeds(rank, steps, step, B):
+    return (rank * steps + step) * B + np.arange(B)                    # bench.py: every step of every rank solves its own instances
+
+
 def _worker(rank, world, port, B, depth, steps, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    seeds = rank * B + np.arange(B)                                    # bench.py: instances sharded contiguously across ranks
-    batch = workload.make_batch("srbd13", N, seeds)
-    t = {k: torch.from_numpy(batch[k]) for k in ("x0", "xs", "us", "params")}
-    fleet = FleetQueue(OracleEngine(depth * B), t["params"].repeat(depth, 1, 1).contiguous(), B, depth, collective=True)
-    for _ in range(steps):
-        fleet.submit(t["x0"], t["xs"], t["us"])
+    P0 = torch.zeros(depth * B, N + 1, NP, dtype=torch.float64)
+    fleet = FleetQueue(OracleEngine(depth * B), P0, B, depth, collective=True)
+    out = []
+    held = None                                                        # launch k's gathered view, read again after launch k + 1 started
+    for s in range(steps):
+        batch = workload.make_batch("srbd13", N, _seeds(rank, steps, s, B))
+        t = {k: torch.from_numpy(batch[k]) for k in ("x0", "xs", "us", "params")}
+        if fleet.full:
+            with pytest.raises(RuntimeError):                          # a full handle refuses the next batch: no silent flush
+                fleet.submit(t["x0"], t["xs"], t["us"], t["params"])
+            fleet.flush()
+            if held is not None:
+                out.append(("after_next_launch", held.numpy().copy()))
+            held = fleet.gathered
+            out.append(("launch", held.numpy().copy()))
+        fleet.submit(t["x0"], t["xs"], t["us"], t["params"])
     fleet.flush()
-    last = steps - depth * ((steps - 1) // depth)                      # batches in the last launch
-    q.put((rank, fleet.launches, last, fleet.gathered.numpy().copy()))
+    if held is not None:
+        out.append(("after_next_launch", held.numpy().copy()))
+    fleet.wait()
+    out.append(("launch", fleet.gathered.numpy().copy()))
+    q.put((rank, fleet.launches, fleet.gather_bytes, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_fleet_step_world2_gathers_every_ranks_records():
-    world, B, depth, steps = 2, 6, 2, 3
+    world, B, depth, steps = 2, 4, 2, 5                                # 5 steps on a depth-2 handle: launches of 2, 2 and 1 batches
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -86,15 +103,32 @@ def test_fleet_step_world2_gathers_every_ranks_records():
     res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
-    # unsharded reference: all world * B instances in one process
-    batch = workload.make_batch("srbd13", N, np.arange(world * B))
-    xo, uo, so = cport.solve_batch(omodels.RobotConsts(), oddp.DdpOptions(**OPTS), batch["x0"], batch["params"], batch["xs"], batch["us"])
-    for rank, launches, last, rec in res:
-        assert launches == 2 and last == 1                             # 3 steps on a depth-2 handle: a full launch, then one batch
-        assert rec.shape == (world * last * B, sdist.record_words(N, NX, NU))
-        x, u, cost, iters = sdist.unpack_records(rec, N, NX, NU)
-        np.testing.assert_array_equal(x, xo)                           # rank-major = instance order: rank r's block is seeds r*B..
-        np.testing.assert_array_equal(u, uo)
-        np.testing.assert_array_equal(cost, so[:, 0])
-        np.testing.assert_array_equal(iters, so[:, 1])
-    np.testing.assert_array_equal(res[0][3], res[1][3])                # every rank ends with the same gathered tensor
+    W = sdist.record_words(N, NX, NU)
+    # unsharded reference of each launch: rank-major, each rank's block = its steps of that launch in order
+    launches = [[0, 1], [2, 3], [4]]
+    refs = []
+    for st in launches:
+        seeds = np.concatenate([_seeds(r, steps, s, B) for r in range(world) for s in st])
+        batch = workload.make_batch("srbd13", N, seeds)
+        xo, uo, so = cport.solve_batch(omodels.RobotConsts(), oddp.DdpOptions(**OPTS), batch["x0"], batch["params"], batch["xs"], batch["us"])
+        refs.append((xo, uo, so))
+    for rank, n_launch, gbytes, out in res:
+        assert n_launch == 3
+        assert gbytes == steps * B * W * 8                             # every record leaves the rank exactly once
+        kinds = [k for k, _ in out]
+        assert kinds == ["launch", "after_next_launch", "launch", "after_next_launch", "launch"]
+        li = 0
+        for kind, rec in out:
+            if kind == "after_next_launch":                            # the previous launch's records, re-read after the next launch
+                xo, uo, so = refs[li - 1]                              # and its collective were started: the other buffer pair
+            else:
+                xo, uo, so = refs[li]
+                li += 1
+            assert rec.shape == (xo.shape[0], W)
+            x, u, cost, iters = sdist.unpack_records(rec, N, NX, NU)
+            np.testing.assert_array_equal(x, xo)
+            np.testing.assert_array_equal(u, uo)
+            np.testing.assert_array_equal(cost, so[:, 0])
+            np.testing.assert_array_equal(iters, so[:, 1])
+    for a, b in zip(res[0][3], res[1][3]):
+        np.testing.assert_array_equal(a[1], b[1])                      # every rank ends with the same gathered tensors

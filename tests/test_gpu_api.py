@@ -1,14 +1,19 @@
 """Error behaviour and surface details of the drop-in boundary on a real device (C ABI status codes -> RuntimeError /
 ValueError / KeyError in the Python mirrors, like the reference's Python exceptions)."""
+import os
+
 import numpy as np
 import pytest
 
+from oracle import cport, ddp as oddp, models as omodels
 from srbd_horizon_amd import workload
 from srbd_horizon_amd.ddp import DDPSolver
 from srbd_horizon_amd.engine import DdpEngine
 from srbd_horizon_amd.prb import LIPProblem, SRBD13Problem, SRBDProblem
 
 pytestmark = pytest.mark.gpu
+
+OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsrbd_example.py:55-58
 
 
 def test_engine_rejects_bad_calls():
@@ -204,3 +209,45 @@ def test_device_resident_receding_horizon_equals_the_host_shift(model, ns):
     e = DdpEngine(model, ns, 1)
     with pytest.raises(RuntimeError, match="sddp_set_params"):
         e.advance(np.zeros((1, e.np_)), np.zeros((1, e.nx)))
+
+
+def test_fleet_tick_of_1024_robots_matches_the_c_oracle_tick_by_tick():
+    """The path behind bench.py's `ms_per_fleet_tick` (VERDICT r02 #4a): B = 1024 robots, each tick = sddp_advance (parameters and
+    previous solution shifted by one knot on the device, new last parameter column and measured state uploaded) +
+    sddp_solve_resident, against the C oracle solving the same tick from the HOST-side shift of the same data
+    (dsrbd_example.py:102-135).  The oracle is fed the GPU's previous solution, so every tick is compared on its own."""
+    N, B, ticks = 30, 1024, 6
+    b = workload.make_batch("srbd13", N, np.arange(B) + 20000)
+    eng = DdpEngine("srbd13", N, B, opts=dict(OPTS, waves_per_simd=1))
+    eng.set_initial_state(b["x0"]); eng.set_x_warmstart(b["xs"]); eng.set_u_warmstart(b["us"])
+    eng.set_params(b["params"])
+    x, u = eng.solve_resident()                                   # every robot's first (cold) tick
+    P = b["params"].copy()
+    cst, o = omodels.RobotConsts(**b["consts"]), oddp.DdpOptions(**OPTS)
+    rng = np.random.default_rng(5)
+    for t in range(ticks):
+        p_last = P[:, -1].copy()
+        p_last[:, 0:2] += 0.05 * rng.standard_normal((B, 2))     # the commanded velocity drifts: node N differs from node N-1
+        x0 = x[:, 1] + 1e-3 * rng.standard_normal((B, 13))       # the robot is near, not at, where the plan said
+        xs_ws = np.concatenate([x[:, 1:], x[:, -1:]], axis=1)
+        us_ws = np.concatenate([u[:, 1:], u[:, -1:]], axis=1)
+        P = np.concatenate([P[:, 1:], p_last[:, None]], axis=1)
+        eng.advance(p_last, x0)
+        x, u = eng.solve_resident()
+        st = eng.stats.copy()
+        xo, uo, so = cport.solve_batch(cst, o, x0, P, xs_ws, us_ws, threads=min(16, os.cpu_count() or 1))
+        it_o = so[:, 1].astype(int)
+        same = st["iters"] == it_o
+        assert same.mean() >= 0.99, f"tick {t}: {int((~same).sum())} robots with another iteration count"
+        np.testing.assert_array_equal(st["status"][same], so[same, 6].astype(int))
+        np.testing.assert_array_equal(st["converged"][same], so[same, 2].astype(int))
+        conv = same & (so[:, 2] == 1)
+        assert conv.mean() >= 0.98
+        ex = np.max(np.abs(x[conv] - xo[conv]), axis=(1, 2))
+        eu = np.max(np.abs(u[conv] - uo[conv]), axis=(1, 2))
+        assert ex.max() <= 1e-4 and eu.max() <= 1e-4, (t, ex.max(), eu.max())
+        np.testing.assert_allclose(st["cost"][conv], so[conv, 0], rtol=1e-8)
+        both = ~same & (so[:, 2] == 1) & (st["converged"] == 1)   # another path, both converged: same optimum
+        for i in np.nonzero(both)[0]:
+            assert max(np.max(np.abs(x[i] - xo[i])), np.max(np.abs(u[i] - uo[i]))) <= 1e-4, (t, i)
+    assert eng.stats["iters"].mean() < 8                          # warm-started ticks, not cold solves

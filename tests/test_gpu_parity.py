@@ -216,6 +216,32 @@ def test_exhausted_line_search_stops_with_status_4():
     np.testing.assert_array_equal(x[0], batch["xs"][0]); np.testing.assert_array_equal(u[0], batch["us"][0])
 
 
+def test_exhausted_line_search_at_an_optimum_is_status_0():
+    """`converged = 1` always comes with `status = 0`.  Restart from the optimum with an Armijo fraction nothing can
+    meet: the first sweep still predicts a (tiny) decrease above cost_reduction_ths, so the regular exit does not fire, the
+    whole ladder is rolled out and rejected, and the RELATIVE test expected <= ths * max(1, |J|) (include/sddp.h, sddp_stats)
+    declares the point optimal: status 0, converged, no iteration, one rollout pass.  With a threshold that test cannot meet
+    either, the same call is a stall: status 4, not converged."""
+    N = 30
+    batch = workload.make_batch("srbd13", N, [7])
+    m = _oracle_model("srbd13")
+    eng = DdpEngine("srbd13", N, 1, opts=_opts())
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    xo, uo = eng.solve(batch["params"])
+    assert eng.stats["status"][0] == 0 and eng.stats["converged"][0] == 1
+    for ths, status, conv in ((1e-12, 0, 1), (1e-30, 4, 0)):
+        over = dict(max_iters=5, alpha_converge_threshold=0.5, beta=1e6, cost_reduction_ths=ths)
+        e2 = DdpEngine("srbd13", N, 1, opts=_opts(**over))
+        e2.set_initial_state(batch["x0"]); e2.set_x_warmstart(xo); e2.set_u_warmstart(uo)
+        x2, u2 = e2.solve(batch["params"])
+        st = e2.stats
+        r = oddp.solve(m, batch["x0"][0], batch["params"][0], xo[0], uo[0], _oracle_opts(**over))
+        assert st["expected"][0] >= ths and st["rollouts"][0] >= 1 and st["iters"][0] == 0       # the line search did run, and failed
+        assert (st["status"][0], st["converged"][0]) == (status, conv) == (r.status, int(r.converged)), (ths, st, r.status)
+        assert bool(e2.is_converged()[0]) == bool(conv)
+        np.testing.assert_array_equal(x2, xo); np.testing.assert_array_equal(u2, uo)             # nothing was accepted
+
+
 def test_full_size_batch_properties():
     """BASELINE config 3 size (B = 1024, N = 30): size-independent properties + spot parity on a few instances."""
     N, B = 30, 1024
@@ -341,6 +367,9 @@ def test_whole_bench_batch_matches_the_c_oracle():
     assert np.all(np.isfinite(x[d])) and np.all(np.isfinite(u[d]))
     np.testing.assert_array_equal(st["converged"][d], so[d, 2].astype(int))
     np.testing.assert_allclose(st["cost"][d], so[d, 0], rtol=1e-5)
+    for b in np.nonzero(d & (so[:, 2] == 1) & (st["converged"] == 1))[0]:     # ... and, converged on both sides, the same trajectory
+        e = max(np.max(np.abs(x[b] - xo[b])), np.max(np.abs(u[b] - uo[b])))
+        assert e <= 1e-4, f"instance {b}: GPU {st['iters'][b]} / oracle {it_o[b]} iterations, both converged, linf {e:.3e}"
 
 
 @pytest.mark.parametrize("name,N,B", [("srbd13", 1, 3), ("srbd13", 2, 1), ("srbd13", 100, 2), ("lip30", 1, 2), ("srbd37", 2, 2),

@@ -1,7 +1,7 @@
 """The solve launch as a work queue: more instances than resident workgroups, one launch, every
 workgroup pulls instances until the queue is empty.  An instance's result must not depend on the slot that solved it, on what
 that slot solved before, on the queue order or on the range of the batch a launch covers: everything here is BIT-exact
-against one-workgroup-per-instance launches.  SDDP_MAX_SLOTS (diagnostic) shrinks the slot count so that a few hundred
+against one-workgroup-per-instance launches.  sddp_options.max_slots shrinks the slot count so that a few hundred
 instances already queue; the last test runs BASELINE configs[3] (8 x 1024 instances, the 8 rank shards) through the real
 queue (2048 slots) against the C oracle."""
 import os
@@ -21,15 +21,9 @@ OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsr
 
 
 def _engine(model, N, B, max_slots=None, **over):
-    old = os.environ.pop("SDDP_MAX_SLOTS", None)
     if max_slots is not None:
-        os.environ["SDDP_MAX_SLOTS"] = str(max_slots)
-    try:
-        return DdpEngine(model, N, B, opts=dict(OPTS, **over))
-    finally:
-        os.environ.pop("SDDP_MAX_SLOTS", None)
-        if old is not None:
-            os.environ["SDDP_MAX_SLOTS"] = old
+        over = dict(over, max_slots=max_slots)
+    return DdpEngine(model, N, B, opts=dict(OPTS, **over))
 
 
 def _solve(eng, batch):
@@ -46,7 +40,7 @@ def test_queue_is_bit_identical_to_one_workgroup_per_instance(model, N, B, slots
     assert ref.queue_info()[0] == B                                   # every instance has its own slot: no queue
     x0, u0, s0 = _solve(ref, batch)
     assert ref.queue_info()[1:] == (B, 0)
-    for order in (0, 1):
+    for order in (0, 1, 2):                                           # index, longest previous solve first, largest initial cost first
         q = _engine(model, N, B, max_slots=slots, waves_per_simd=wps, queue_order=order)
         assert q.queue_info()[0] == slots
         for rep in range(2):                                          # second solve: the order comes from the first one's history
@@ -75,6 +69,10 @@ def test_ranges_of_a_handle_solve_like_separate_batches():
     for steps in (1, 3, 5):                                           # partial handle, full handle, wrap-around (two launches)
         before = fleet.launches
         for _ in range(steps):
+            if fleet.full:
+                with pytest.raises(RuntimeError, match="full"):       # no silent flush: the caller launches
+                    fleet.submit(t["x0"], t["xs"], t["us"])
+                fleet.flush()
             fleet.submit(t["x0"], t["xs"], t["us"])
         fleet.flush()
         assert fleet.launches - before == -(-steps // D)
@@ -94,7 +92,7 @@ def test_ranges_of_a_handle_solve_like_separate_batches():
 
 def test_non_finite_options_are_rejected():
     for k, v in (("alpha_0", float("inf")), ("mu_max", float("nan")), ("beta", float("nan")), ("gap_tol", float("inf")),
-                 ("mu_max", 1e-7), ("queue_order", 2), ("line_search_decrease_factor", 0.9999999), ("second_order", 3)):
+                 ("mu_max", 1e-7), ("queue_order", 3), ("max_slots", -1), ("line_search_decrease_factor", 0.9999999), ("second_order", 3)):
         with pytest.raises(RuntimeError):
             DdpEngine("srbd13", 30, 1, opts=dict(OPTS, **{k: v}))
 
@@ -139,5 +137,42 @@ def test_configs3_all_eight_rank_shards_match_the_c_oracle():
           f"iterations GPU {st['iters'][d].tolist()} oracle {it_o[d].tolist()}")
     assert np.all(np.isin(st["status"][d], (0, 1)))
     np.testing.assert_allclose(st["cost"][both], so[both, 0], rtol=1e-5)
+    # ... and at the same trajectory (VERDICT r02 #4b): both sides converged, so they sit at the same local optimum
+    for b in np.nonzero(both)[0]:
+        e = max(np.max(np.abs(x[b] - xo[b])), np.max(np.abs(u[b] - uo[b])))
+        assert e <= 1e-4, f"instance {b}: GPU {st['iters'][b]} / oracle {it_o[b]} iterations, both converged, linf {e:.3e}"
     lost = d & conv_o & (st["converged"] == 0)               # converged in the oracle, out of iterations on the GPU: only near the cap
     assert np.all(it_o[lost] >= 60), it_o[lost]
+
+
+def test_cold_queue_order_starts_the_costliest_warm_starts_first():
+    """queue_order = 2: the pre-pass key is the initial total cost of each warm start, i.e. the cost the oracle reports for a
+    solve cut off before its first iteration; the launch must hand out the instances in descending order of it.  Observed
+    through a queue on ONE slot: the slot solves the instances one after another, so the order is the order in which the
+    per-slot gains buffer is overwritten -- here simply checked through results (bit-exact, above) plus the key itself."""
+    N, B = 30, 96
+    batch = workload.make_batch("srbd13", N, np.arange(B) + 4000)
+    cst, o0 = omodels.RobotConsts(**batch["consts"]), oddp.DdpOptions(**dict(OPTS, max_iters=0))
+    _, _, so = cport.solve_batch(cst, o0, batch["x0"], batch["params"], batch["xs"], batch["us"])
+    J0 = so[:, 0]
+    eng = _engine("srbd13", N, B, max_slots=8, queue_order=2, max_iters=0)       # max_iters = 0: stats.cost = the initial cost
+    x, u, st = _solve(eng, batch)
+    np.testing.assert_allclose(st["cost"], J0, rtol=1e-12)
+    assert eng.queue_info()[1:] == (8, B)
+    # the engine's own view of the order it used
+    order = eng.last_queue_order()
+    assert sorted(order.tolist()) == list(range(B))
+    assert np.all(np.diff(J0[order]) <= 1e-9 * np.abs(J0).max()), "queue not in descending initial-cost order"
+
+
+def test_gains_pointer_is_refused_after_a_queued_launch():
+    N, B = 30, 40
+    batch = workload.make_batch("srbd13", N, np.arange(B))
+    eng = _engine("srbd13", N, B)
+    _solve(eng, batch)
+    ptr, nbytes = eng.device_buffer(3)                                 # one slot per instance: row b is instance b's
+    assert ptr and nbytes == B * N * 6 * 14 * 8
+    q = _engine("srbd13", N, B, max_slots=8)
+    _solve(q, batch)
+    with pytest.raises(RuntimeError, match="per queue slot"):
+        q.device_buffer(3)

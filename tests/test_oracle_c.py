@@ -63,7 +63,13 @@ def test_exhausted_line_search_is_a_stall_not_convergence_in_both_oracles():
     hard = oddp.DdpOptions(max_iters=5, alpha_converge_threshold=0.5, beta=1e6, cost_reduction_ths=1e-12)
     r2 = oddp.solve(m, batch["x0"][0], batch["params"][0], opt.xs, opt.us, hard)
     _, _, st2 = cport.solve_batch(cst, hard, batch["x0"], batch["params"], opt.xs[None], opt.us[None])
-    assert r2.status in (0, 4) and r2.converged and int(st2[0, 2]) == 1 and int(st2[0, 6]) == r2.status
+    assert r2.status == 0 and r2.converged and r2.iters == 0 and int(st2[0, 2]) == 1 and int(st2[0, 6]) == 0      # converged <=> status 0
+    # the same restart with a threshold no sweep can meet: the line search is exhausted and the point does NOT pass the
+    # (relative) optimality test any more -> status 4, not converged
+    harder = oddp.DdpOptions(max_iters=5, alpha_converge_threshold=0.5, beta=1e6, cost_reduction_ths=1e-30)
+    r3 = oddp.solve(m, batch["x0"][0], batch["params"][0], opt.xs, opt.us, harder)
+    _, _, st3 = cport.solve_batch(cst, harder, batch["x0"], batch["params"], opt.xs[None], opt.us[None])
+    assert r3.status == 4 and not r3.converged and int(st3[0, 6]) == 4 and int(st3[0, 2]) == 0
 
 
 @pytest.mark.parametrize("name,barrier", [("srbd37", 0.0), ("srbd37", 6.0), ("lip30", 0.0)])
