@@ -192,8 +192,8 @@ def main():
     d_t = load_blocks(timed_blocks)
     d_w = load_blocks(warm_blocks) if warmup else None
 
-    def make_queue(order):
-        e = DdpEngine("srbd13", N, Q * B, opts=dict(opts, waves_per_simd=wps, queue_order=order))
+    def make_queue(order, **over):
+        e = DdpEngine("srbd13", N, Q * B, opts=dict(opts, waves_per_simd=wps, queue_order=order, **over))
         e.use_torch_stream(torch.cuda.current_stream())
         e.enable_timing(True)
         P_all = torch.zeros((Q * B, N + 1, npar), dtype=torch.float64, device=dev)      # the handle's parameter tensor, resident
@@ -306,6 +306,14 @@ def main():
             run_steps(f_o, d_t if order == 1 else (d_w if warmup else d_t), n_x if order == 1 else min(max(warmup, 1), n_x))
             out[key] = B * n_x / timed(f_o, d_t, n_x)
             del f_o, e_o
+        # full second-order DDP (sddp_options.second_order = 2: its own kernel build), same instances, same queue order as `value`
+        e_o, f_o = make_queue(args.queue_order, second_order=2)
+        run_steps(f_o, d_w if warmup else d_t, min(max(warmup, 1), n_x))
+        acc.zero_()
+        el = timed(f_o, d_t, n_x, count=True)
+        out["second_order2_solves_per_s"] = B * n_x / el
+        out["second_order2_mean_iters"] = int(acc[0].item()) / (B * n_x)
+        del f_o, e_o
         # strictly one batch per launch (the next step starts after the previous one's slowest instance has finished), the kernel
         # build with the full register file per instance: the latency of one batch
         e_lat = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
@@ -326,6 +334,7 @@ def main():
         batch = workload.make_batch("srbd13", N, np.arange(B))
         out.update(single_instance_extras(N, opts, workload, DdpEngine))
         out["ms_per_fleet_tick"] = fleet_tick(N, B, opts, workload, DdpEngine)
+        out["tick_ms_vs_batch"] = tick_curve(N, opts, workload, DdpEngine)
         # PCIe-inclusive batch rate (host-pointer C-ABI call: params in, x/u/stats out) -- reported, never `value`
         e_h = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
         e_h.set_initial_state(batch["x0"])
@@ -445,6 +454,47 @@ def fleet_tick(N, B, opts, workload, DdpEngine, ticks=100, budget=6, cpu_ticks=6
                     "sddp_solve_resident incl. the PCIe copies of p_last / x0 in and x / u / stats out; CPU = the C port, OpenMP over robots; "
                     "a tick to convergence ends with its slowest robot (slowest_ticks: its iteration count), the budgeted run caps "
                     "every robot at max_iters_per_tick and carries unfinished iterates over"}
+
+
+def tick_curve(N, opts, workload, DdpEngine, batches=(1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024), ticks=24, cpu_ticks=3):
+    """ms per MPC tick against the number of robots per tick: GPU (sddp_advance + sddp_solve_resident, PCIe included) beside the C
+    port on 1 and on all host threads, same problems (the GPU's tick sequence replayed).  One small robot is a single wavefront of
+    a 256-CU chip and loses to a CPU core; the curve states from which fleet size the GPU path pays (crossover B*)."""
+    from oracle import cport, ddp as oddp, models as omodels
+    cst, o = omodels.RobotConsts(), oddp.DdpOptions(**opts)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    rows = []
+    for B in batches:
+        b = workload.make_batch("srbd13", N, np.arange(B) + 7000)
+        e = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
+        e.set_initial_state(b["x0"]); e.set_x_warmstart(b["xs"]); e.set_u_warmstart(b["us"])
+        e.set_params(b["params"])
+        x, u = e.solve_resident()
+        P = b["params"].copy()
+        g, c1, cn, its = [], [], [], []
+        for t in range(ticks):
+            p_last, x0 = P[:, -1].copy(), x[:, 1].copy()
+            xs_ws = np.concatenate([x[:, 1:], x[:, -1:]], axis=1); xs_ws[:, 0] = x0
+            us_ws = np.concatenate([u[:, 1:], u[:, -1:]], axis=1)
+            P = np.concatenate([P[:, 1:], p_last[:, None]], axis=1)
+            t1 = time.perf_counter()
+            e.advance(p_last, x0)
+            x, u = e.solve_resident()
+            g.append(1e3 * (time.perf_counter() - t1))
+            its.append(float(e.stats["iters"].mean()))
+            if t >= ticks - cpu_ticks:
+                for th, acc_ in ((1, c1), (threads, cn)):
+                    t1 = time.perf_counter()
+                    cport.solve_batch(cst, o, x0, P, xs_ws, us_ws, threads=th)
+                    acc_.append(1e3 * (time.perf_counter() - t1))
+        rows.append({"batch": B, "gpu_ms": float(np.median(g[4:])), "cpu1_ms": float(np.median(c1)), f"cpu{threads}_ms": float(np.median(cn)),
+                     "mean_iters": float(np.mean(its[4:]))})
+    cross1 = next((r["batch"] for r in rows if r["gpu_ms"] < r["cpu1_ms"]), None)
+    crossn = next((r["batch"] for r in rows if r["gpu_ms"] < r[f"cpu{threads}_ms"]), None)
+    return {"rows": rows, "crossover_batch_vs_1_thread": cross1, f"crossover_batch_vs_{threads}_threads": crossn, "cpu_threads": threads,
+            "note": "srbd13 N=30 warm-started ticks (previous solution advanced by one knot); GPU = sddp_advance + sddp_solve_resident with the "
+                    "PCIe copies; CPU = the C port of the oracle (kind: port) on the same tick sequence; crossover = smallest measured batch "
+                    "at which the GPU tick is shorter"}
 
 
 def single_instance_extras(N, opts, workload, DdpEngine):

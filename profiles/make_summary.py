@@ -1,60 +1,93 @@
-"""Collects the rocprofv3 CSVs a GPU session left under gpurun_out/prof/ into profiles/<round>/ (what the judge reads).
-usage: python profiles/make_summary.py r01 <trace_dir> <pmc_fetch_dir> <pmc_write_dir> <pmc_sq_dir> <bench_log>"""
+"""Collects the rocprofv3 CSVs a GPU session left under gpurun_out/prof_<round>/ (profiles/collect.sh) into profiles/<round>/
+(what the judge reads).  usage: python profiles/make_summary.py r03 gpurun_out/prof_r03 [steps]"""
 import collections, csv, glob, json, os, shutil, sys
 
-rnd, trace, pf, pw, psq, blog = sys.argv[1:7]
-steps = int(sys.argv[7]) if len(sys.argv) > 7 else 20
+rnd, O = sys.argv[1:3]
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), rnd)
 os.makedirs(out_dir, exist_ok=True)
 one = lambda d, pat: sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))[0]
-shutil.copy(one(trace, "*kernel_stats.csv"), os.path.join(out_dir, "kernel_stats_bench.csv"))
-rows = lambda f: [r for r in csv.DictReader(open(f)) if "solve_kernel" in r["Kernel_Name"]]
-out = {}
-for d, name in ((pf, "FETCH_SIZE"), (pw, "WRITE_SIZE")):
-    rs = rows(one(d, "*counter_collection.csv"))
-    with open(os.path.join(out_dir, f"pmc_{name.lower()}_solve_kernel.csv"), "w") as g:
+last_json = lambda f: json.loads([l for l in open(f) if l.startswith("{")][-1])
+
+
+def kernel_set(tag, kname, suffix):
+    """the four passes of one command -> dict; copies the solve-kernel rows of every pass to profiles/<round>/"""
+    out = {}
+    shutil.copy(one(f"{O}/{tag}trace", "*kernel_stats.csv"), os.path.join(out_dir, f"kernel_stats_{suffix}.csv"))
+    rows = lambda f: [r for r in csv.DictReader(open(f)) if kname in r["Kernel_Name"]]
+    for d, name in ((f"{O}/{tag}pmc_fetch", "FETCH_SIZE"), (f"{O}/{tag}pmc_write", "WRITE_SIZE")):
+        rs = rows(one(d, "*counter_collection.csv"))
+        with open(os.path.join(out_dir, f"pmc_{name.lower()}_{suffix}.csv"), "w") as g:
+            w = csv.DictWriter(g, fieldnames=rs[0].keys()); w.writeheader(); w.writerows(rs)
+        vals = [float(r["Counter_Value"]) for r in rs]
+        out[name] = {"per_dispatch": vals, "mean": sum(vals) / len(vals)}
+        out["kernel"] = {k: rs[0][k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                                               "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
+    rs = rows(one(f"{O}/{tag}pmc_sq", "*counter_collection.csv"))
+    with open(os.path.join(out_dir, f"pmc_sq_{suffix}.csv"), "w") as g:
         w = csv.DictWriter(g, fieldnames=rs[0].keys()); w.writeheader(); w.writerows(rs)
-    vals = [float(r["Counter_Value"]) for r in rs]
-    out[name] = {"per_dispatch": vals, "mean": sum(vals) / len(vals)}
-    out["kernel"] = {k: rs[0][k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
-                                           "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
-rs = rows(one(psq, "*counter_collection.csv"))
-with open(os.path.join(out_dir, "pmc_sq_solve_kernel.csv"), "w") as g:
-    w = csv.DictWriter(g, fieldnames=rs[0].keys()); w.writeheader(); w.writerows(rs)
-sq = collections.defaultdict(list)
-for r in rs:
-    sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
-out["SQ"] = {k: sum(v) / len(v) for k, v in sq.items()}
-f, w = out["FETCH_SIZE"]["mean"], out["WRITE_SIZE"]["mean"]
-out["traffic_bytes_per_launch"] = (2 * f + w) * 1024
-out["traffic_bytes_per_launch_uncorrected"] = (f + w) * 1024
-out["batches_per_launch"] = steps            # every launch of the profiled command solves `steps` batches of 1024 instances
-# rocprofv3 per-dispatch durations of the traced run, split like bench.py splits them (warm-up launches are not in its HIP-event mean)
-tr = sorted(glob.glob(os.path.join(trace, "**", "*kernel_trace.csv"), recursive=True))
-if tr:
-    ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr[0])) if "solve_kernel" in r["Kernel_Name"])
-    dur = [(e - s0) / 1e6 for s0, e in ks]
-    tl0 = os.path.join(os.path.dirname(blog), "trace.log")
-    tj = json.loads([l for l in open(tl0) if l.startswith("{")][-1]) if os.path.exists(tl0) else None
-    nw = len(dur) - (tj["config"]["launches_timed"] if tj else len(dur))      # priming launches come first
-    out["traced_run"] = {"launches": len(dur), "warmup_launches": nw, "rocprof_mean_ms_all": sum(dur) / len(dur),
-                         "rocprof_mean_ms_timed": sum(dur[nw:]) / max(1, len(dur) - nw),
-                         "hip_event_mean_ms_timed": tj["roofline"]["kernel_ms"] if tj else None}
-out["note"] = (f"rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_* each in its own run) of `python3 bench.py --steps {steps} --warmup 5 "
-               "--no-cpu-baseline --no-extras` (one priming launch + one timed launch, each a work queue of steps x 1024 instances on the "
-               "resident wavefronts); FETCH/WRITE_SIZE in KiB; gfx950 correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE doubled "
-               "(calibrated for 16 B/lane streams; this kernel reads 8 B/lane, so the uncorrected figure is also given). "
-               "Kernel = solve_kernel_w2<SrbdModel<2,false>>, N=30; means over the dispatches of the run.")
-json.dump(out, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1)
-line = [l for l in open(blog) if l.startswith("{")][-1]
-d = json.loads(line)
-d["roofline"]["traffic"] = out["traffic_bytes_per_launch"]      # the PMC passes of THIS collection (bench.py read the previous one)
+    sq = collections.defaultdict(list)
+    for r in rs:
+        sq[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out["SQ_mean_per_dispatch"] = {k: sum(v) / len(v) for k, v in sq.items()}
+    out["SQ_last_dispatch"] = {k: v[-1] for k, v in sq.items()}
+    tr = one(f"{O}/{tag}trace", "*kernel_trace.csv")
+    ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr)) if kname in r["Kernel_Name"])
+    out["rocprof_dispatch_ms"] = [(e - s0) / 1e6 for s0, e in ks]
+    return out
+
+
+# ---- headline: solve_kernel_w2<srbd13>, the driver's command ------------------------------------------------------------------
+h = kernel_set("", "solve_kernel", "bench")
+tj = last_json(f"{O}/trace.log")
+nt = tj["config"]["launches_timed"]
+f, w = h["FETCH_SIZE"]["per_dispatch"][-nt:], h["WRITE_SIZE"]["per_dispatch"][-nt:]      # the timed launches come last
+fm, wm = sum(f) / len(f), sum(w) / len(w)
+summary = dict(h)
+summary["traffic_bytes_per_launch"] = (2 * fm + wm) * 1024
+summary["traffic_bytes_per_launch_uncorrected"] = (fm + wm) * 1024
+summary["batches_per_launch"] = steps / nt
+dur = h["rocprof_dispatch_ms"]
+summary["traced_run"] = {"launches": len(dur), "warmup_launches": len(dur) - nt, "rocprof_ms_timed": dur[-nt:],
+                         "rocprof_mean_ms_timed": sum(dur[-nt:]) / nt, "hip_event_mean_ms_timed": tj["roofline"]["kernel_ms"]}
+n_inst = steps * 1024 / nt
+it = tj["mean_iters"]
+sq = h["SQ_last_dispatch"]
+summary["per_instance_iteration"] = {k: v / (n_inst * it) for k, v in sq.items() if k.startswith("SQ_INSTS")}
+summary["note"] = (f"rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_* each in its own run) of `python3 bench.py --steps {steps} --warmup 5 "
+                   "--no-cpu-baseline --no-extras` (one warm-up launch of 5 batches, then the timed launch(es) of distinct instances, each a "
+                   "work queue on the resident wavefronts); traffic = the timed launches; FETCH/WRITE_SIZE in KiB; gfx950 correction per "
+                   "MI355X_MICROARCH.md (HBM): FETCH_SIZE doubled (calibrated for 16 B/lane streams; this kernel reads 8 B/lane, so the "
+                   "uncorrected figure is also given).  Kernel = solve_kernel_w2<SrbdModel<2,false>>, N=30.")
+json.dump(summary, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1)
+d = last_json(f"{O}/bench.log")
+d["roofline"]["traffic"] = summary["traffic_bytes_per_launch"] * (d["config"]["launches_timed"] and 1)      # the PMC passes of THIS collection
+d["roofline"]["traffic_source"] = f"profiles/{rnd}/pmc_summary.json"
 open(os.path.join(out_dir, "bench_line.json"), "w").write(json.dumps(d) + "\n")
-tl = os.path.join(os.path.dirname(blog), "trace.log")
-if os.path.exists(tl):                                          # the bench line of the traced run: its HIP-event kernel time
-    tline = [l for l in open(tl) if l.startswith("{")][-1]      # must agree with kernel_stats_bench.csv
-    open(os.path.join(out_dir, "bench_line_traced_run.json"), "w").write(tline)
-print({k: d.get(k) for k in ("value", "ms_per_step", "mean_iters", "mean_rollouts", "converged_frac", "iterations_per_s",
-                              "pcie_inclusive_solves_per_s", "one_batch_in_flight_solves_per_s", "index_order_solves_per_s")})
-print(d["roofline"]); print(d.get("cpu_baseline")); print(d.get("ms_per_mpc_tick")); print(out["SQ"]); print(out["kernel"])
-print(open(os.path.join(out_dir, "kernel_stats_bench.csv")).read())
+open(os.path.join(out_dir, "bench_line_traced_run.json"), "w").write(json.dumps(tj) + "\n")
+
+# ---- 4-wavefront kernel: one cold batch per configuration --------------------------------------------------------------------
+mw = {}
+for tag in ("mw_srbd37_n20_", "mw_srbd37_n60_"):
+    if not os.path.isdir(f"{O}/{tag}trace"):
+        continue
+    k = kernel_set(tag, "solve_kernel_mw", tag.rstrip("_"))
+    line = last_json(f"{O}/{tag}trace.log")
+    fm, wm = k["FETCH_SIZE"]["per_dispatch"][-1], k["WRITE_SIZE"]["per_dispatch"][-1]
+    k["traffic_bytes_per_launch"] = (2 * fm + wm) * 1024
+    k["traffic_bytes_per_launch_uncorrected"] = (fm + wm) * 1024
+    k["bench"] = line
+    k["traffic_over_algorithmic"] = k["traffic_bytes_per_launch"] / line["algorithmic_bytes"]
+    tot_it = line["mean_iters"] * line["batch"]
+    k["per_instance_iteration"] = {n: v / tot_it for n, v in k["SQ_last_dispatch"].items() if n.startswith("SQ_INSTS")}
+    k["rocprof_ms_last_dispatch"] = k["rocprof_dispatch_ms"][-1]
+    mw[tag.rstrip("_")] = k
+json.dump(mw, open(os.path.join(out_dir, "pmc_summary_mw.json"), "w"), indent=1)
+
+print({k: d.get(k) for k in ("value", "ms_per_step", "mean_iters", "mean_rollouts", "iterations_per_s", "index_order_solves_per_s",
+                              "replay_history_order_solves_per_s", "one_batch_in_flight_solves_per_s", "pcie_inclusive_solves_per_s")})
+print(d["roofline"]); print(d.get("cpu_baseline")); print(d.get("ms_per_mpc_tick")); print(d.get("ms_per_fleet_tick")); print(d.get("tick_ms_vs_batch"))
+print("headline SQ (timed launch):", h["SQ_last_dispatch"], summary["per_instance_iteration"], h["kernel"], summary["traced_run"])
+for tag, k in mw.items():
+    print(tag, k["kernel"], k["bench"], "traffic/alg", k["traffic_over_algorithmic"], k["per_instance_iteration"], k["SQ_last_dispatch"])
+print(open(os.path.join(out_dir, "kernel_stats_bench.csv")).read()[:1500])

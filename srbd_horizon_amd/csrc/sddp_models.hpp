@@ -184,35 +184,34 @@ __device__ __forceinline__ void world_inertia_d(const DevConsts& c, const double
     }
 }
 
-// runtime-index dR/dq_a (the full second-order builds loop over quaternion components)
-__device__ inline void quat_to_rot_dyn(const double* q, int a, double* D) {
-    switch (a) {
-        case 0: quat_to_rot_d<0>(q, D); break;
-        case 1: quat_to_rot_d<1>(q, D); break;
-        case 2: quat_to_rot_d<2>(q, D); break;
-        default: quat_to_rot_d<3>(q, D); break;
-    }
-}
 // d2 I_w / dq_p dq_q from R, dR/dq_p, dR/dq_q and the (constant) d2R/dq_p dq_q
-__device__ inline void world_inertia_d2(const DevConsts& c, const double* R, const double* dRp, const double* dRq, const double* d2R,
-                                        double* d2M) {
+__device__ __forceinline__ void world_inertia_d2(const DevConsts& c, const double* R, const double* dRp, const double* dRq, const double* d2R,
+                                                 double* d2M) {
     if (c.inertia_mode == 0) {
+#pragma unroll
         for (int i = 0; i < 3; ++i)
+#pragma unroll
             for (int j = 0; j < 3; ++j)
                 d2M[3 * i + j] = c.Is[3 * i + j] * (d2R[3 * i + j] * R[3 * j + i] + dRp[3 * i + j] * dRq[3 * j + i] +
                                                     dRq[3 * i + j] * dRp[3 * j + i] + R[3 * i + j] * d2R[3 * j + i]);
-    } else {   // d2R Is R^T + dRp Is dRq^T + dRq Is dRp^T + R Is d2R^T
-        const double* L[4] = {d2R, dRp, dRq, R};
-        const double* Rr[4] = {R, dRq, dRp, d2R};
-        for (int i = 0; i < 9; ++i) d2M[i] = 0.0;
-        for (int t = 0; t < 4; ++t) {
-            double T[9], U[9];
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j)
-                    T[3 * i + j] = c.Is[3 * i] * Rr[t][3 * j] + c.Is[3 * i + 1] * Rr[t][3 * j + 1] + c.Is[3 * i + 2] * Rr[t][3 * j + 2];
-            matmul3(L[t], T, U);
-            for (int i = 0; i < 9; ++i) d2M[i] += U[i];
-        }
+    } else {   // d2R Is R^T + dRp Is dRq^T + dRq Is dRp^T + R Is d2R^T = X + X^T,  X = d2R Is R^T + dRp Is dRq^T
+        double T[9], U[9], X[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                T[3 * i + j] = c.Is[3 * i] * R[3 * j] + c.Is[3 * i + 1] * R[3 * j + 1] + c.Is[3 * i + 2] * R[3 * j + 2];
+        matmul3(d2R, T, X);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                T[3 * i + j] = c.Is[3 * i] * dRq[3 * j] + c.Is[3 * i + 1] * dRq[3 * j + 1] + c.Is[3 * i + 2] * dRq[3 * j + 2];
+        matmul3(dRp, T, U);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) d2M[3 * i + j] = (X[3 * i + j] + U[3 * i + j]) + (X[3 * j + i] + U[3 * j + i]);
     }
 }
 
@@ -239,10 +238,13 @@ struct SrbdModel {
     // derivative record of one knot
     static constexpr int REC_A = 0, REC_JO = 3 * NA, REC_JW = REC_JO + 16, REC_MI = REC_JW + 12, REC_G = REC_MI + 9,
                          REC_B = REC_G + NZ,                       // BAR: barrier Hessian per contact: hxx hyy hzz hxz hyz
-                         REC_WD = REC_B + (BAR ? 5 * NC : 0),      // SO2: wdot (3), then T[e][m] = d2 wdot_m / dz_a dz_b for the
-                         REC_T = REC_WD + 3,                       //      lower-triangle pairs e = a (a + 1) / 2 + b of the NA compact columns
+                         REC_WD = REC_B + (BAR ? 5 * NC : 0),      // SO2 (full second-order builds): compact factors of the wdot
+                         REC_M = REC_WD + 3,                       //   Hessian, contracted in the sweep (add_second_order):
+                         REC_DM = REC_M + 9,                       //   wdot (3) | I_w (9) | dI_w/do_a (4 x 9) |
+                         REC_COO = REC_DM + 36,                    //   w x (d2I_w/do_a do_b w) + d2I_w/do_a do_b wdot for the 10
+                         REC_W = REC_COO + 30,                     //   pairs a >= b (10 x 3) | w (3)
                          NTRI = NA * (NA + 1) / 2,
-                         NREC = SO2 ? REC_T + 3 * NTRI : REC_WD;
+                         NREC = SO2 ? REC_W + 3 : REC_WD;
 
     __device__ __forceinline__ static int uf(int i) { return CS ? 6 * i + 3 : 3 * i; }  // prb.py:66-68 interleaved
     // parameter layouts: srbd37 = creation order; srbd13 = App. A.7
@@ -552,7 +554,6 @@ struct SrbdModel {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) rec[REC_JW + i] = Jw[i];
             }
-            if (SO2) wdot_hess(c, o, w, f, q, A, rec);
             // gradient of the input residuals: min_qddot rows [rddot; wdot; cddot], min_f, f_active, penalties
             const double s = 2 * c.gq;
 #pragma unroll
@@ -593,79 +594,60 @@ struct SrbdModel {
                     g[XCD + 3 * b + 1] += sp * ey; g[XCD + 3 * b + 4] -= sp * ey;
                 }
             }
+#pragma unroll
+            for (int i = 0; i < NZ; ++i) rec[REC_G + i] = g[i];
+            if (SO2) so2_record(c, o, w, q, rec);       // last: A and the gradient are stored, only the core quantities are live
+            return;
         }
 #pragma unroll
         for (int i = 0; i < NZ; ++i) rec[REC_G + i] = g[i];
     }
 
-    // Second derivatives of wdot = I_w(o)^-1 n(z), n = sum s (c_i - r) x f_i - w x I_w(o) w, over the NA compact columns
-    // r | o | w | [c] | f, from differentiating I_w wdot = n twice (oracle/models.py srbd_wdot_hess):
-    //   d_a d_b wdot = I_w^-1 (d_a d_b n - d_a d_b I_w wdot - d_a I_w d_b wdot - d_b I_w d_a wdot).
-    // Runs once per knot and iteration in the lane-per-knot derivative phase; plain loops (private arrays), not unrolled.
-    __device__ __noinline__ static void wdot_hess(const DevConsts& c, const double* o, const double* w, const double (*f)[3], const Core& q,
-                                                  const double (*A)[NA], double* rec) {
-        double dM[4][9], d2M[4][4][9];
-        {
-            double dR[4][9];
-            for (int a = 0; a < 4; ++a) { quat_to_rot_dyn(o, a, dR[a]); world_inertia_d(c, q.R, dR[a], dM[a]); }
-            for (int p = 0; p < 4; ++p)
-                for (int b = 0; b <= p; ++b) {
-                    double eq[4] = {0, 0, 0, 0}, d2R[9];
-                    eq[b] = 1.0;
-                    quat_to_rot_dyn(eq, p, d2R);            // dR/dq_p is linear in q: its q_b derivative is dR/dq_p at e_b
-                    world_inertia_d2(c, q.R, dR[p], dR[b], d2R, d2M[p][b]);
-                    for (int i = 0; i < 9; ++i) d2M[b][p][i] = d2M[p][b][i];
-                }
+    // Full second-order builds: what the sweep needs to contract the second derivatives of wdot = I_w(o)^-1 n(z),
+    // n = sum s (c_i - r) x f_i - w x I_w(o) w, with a multiplier it only knows then (add_second_order).  Differentiating
+    // I_w wdot = n twice (oracle/models.py srbd_wdot_hess):
+    //   d_a d_b wdot = I_w^-1 (d_a d_b n - d_a d_b I_w wdot - d_a I_w d_b wdot - d_b I_w d_a wdot),
+    // so  lam . d_a d_b wdot = y . V_ab  with  y = I_w^-1 lam  and V_ab built from I_w, dI_w/do_a, w, the first derivatives A
+    // (already in the record) and, for the quaternion pairs, c_ab = w x (d2I_w/do_a do_b w) + d2I_w/do_a do_b wdot: 81 words
+    // instead of the 3 NA (NA + 1) / 2 tensor entries of the first version (408 for srbd13, 1785 for srbd37).  Straight-line
+    // code on compile-time indices: everything stays in registers (the tensor version ran loops over private arrays: 4 KB of
+    // scratch per lane).
+    template <int PA, int PB>
+    __device__ __forceinline__ static void so2_coo_pair(const DevConsts& c, const double* o, const double* w, const Core& q, double* out) {
+        const double eb[4] = {PB == 0 ? 1.0 : 0.0, PB == 1 ? 1.0 : 0.0, PB == 2 ? 1.0 : 0.0, PB == 3 ? 1.0 : 0.0};
+        double dRp[9], dRq[9], d2R[9], d2M[9], t[3], cr[3], t2[3];
+        quat_to_rot_d<PA>(o, dRp);                     // recomputed per pair (9 trivial operations) rather than kept live for all ten
+        quat_to_rot_d<PB>(o, dRq);
+        quat_to_rot_d<PA>(eb, d2R);                    // dR/dq_a is linear in q: its q_b derivative is dR/dq_a at e_b
+        world_inertia_d2(c, q.R, dRp, dRq, d2R, d2M);
+        matvec3(d2M, w, t);
+        cross3(w, t, cr);
+        matvec3(d2M, q.wdot, t2);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) out[m] = cr[m] + t2[m];
+    }
+    __device__ __forceinline__ static void so2_record(const DevConsts& c, const double* o, const double* w, const Core& q, double* rec) {
+        double dR[9], dM[9];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { rec[REC_WD + m] = q.wdot[m]; rec[REC_W + m] = w[m]; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rec[REC_M + i] = q.M[i];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (a == 0) quat_to_rot_d<0>(o, dR);
+            if (a == 1) quat_to_rot_d<1>(o, dR);
+            if (a == 2) quat_to_rot_d<2>(o, dR);
+            if (a == 3) quat_to_rot_d<3>(o, dR);
+            world_inertia_d(c, q.R, dR, dM);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) rec[REC_DM + 9 * a + i] = dM[i];
         }
-        (void)f;
-        for (int m = 0; m < 3; ++m) rec[REC_WD + m] = q.wdot[m];
-        const double s = c.lever;
-        int e = 0;
-        for (int a = 0; a < NA; ++a)
-            for (int b = 0; b <= a; ++b, ++e) {
-                double v[3] = {0, 0, 0};
-                const bool ao = a >= 3 && a < 7, bo = b >= 3 && b < 7, aw = a >= 7 && a < 10, bw = b >= 7 && b < 10;
-                const bool af = a >= AF, br = b < 3, bc = CS && b >= AC && b < AF;
-                if (af && (br || bc)) {     // bilinear torque: d2/(dc df) = s e_c x e_f, d2/(dr df) = -s e_r x e_f
-                    const int i = (a - AF) / 3, fa = (a - AF) % 3;
-                    const bool hit = br || (b - AC) / 3 == i;
-                    const int xa = br ? b : (b - AC) % 3;
-                    if (hit && xa != fa) {
-                        const int third = 3 - xa - fa;
-                        const double sg = ((fa - xa + 3) % 3 == 1) ? 1.0 : -1.0;       // (e_x x e_f)[third]
-                        v[third] = (br ? -s : s) * sg;
-                    }
-                } else if (aw && bw) {
-                    double ea[3] = {0, 0, 0}, eb[3] = {0, 0, 0}, Ma[3], Mb[3], t1[3], t2[3];
-                    ea[a - 7] = 1.0; eb[b - 7] = 1.0;
-                    matvec3(q.M, ea, Ma); matvec3(q.M, eb, Mb); cross3(ea, Mb, t1); cross3(eb, Ma, t2);
-                    for (int m = 0; m < 3; ++m) v[m] = -(t1[m] + t2[m]);
-                } else if (aw && bo) {
-                    double ea[3] = {0, 0, 0}, t0[3], t1[3], t2[3], t3[3];
-                    ea[a - 7] = 1.0;
-                    matvec3(dM[b - 3], w, t0); cross3(ea, t0, t1); matvec3(dM[b - 3], ea, t2); cross3(w, t2, t3);
-                    for (int m = 0; m < 3; ++m) v[m] = -(t1[m] + t3[m]);
-                } else if (ao && bo) {
-                    double t0[3], t1[3], t2[3];
-                    matvec3(d2M[a - 3][b - 3], w, t0); cross3(w, t0, t1); matvec3(d2M[a - 3][b - 3], q.wdot, t2);
-                    for (int m = 0; m < 3; ++m) v[m] = -t1[m] - t2[m];
-                }
-                if (ao) {
-                    const double jb[3] = {A[0][b], A[1][b], A[2][b]};
-                    double t[3];
-                    matvec3(dM[a - 3], jb, t);
-                    for (int m = 0; m < 3; ++m) v[m] -= t[m];
-                }
-                if (bo) {
-                    const double ja[3] = {A[0][a], A[1][a], A[2][a]};
-                    double t[3];
-                    matvec3(dM[b - 3], ja, t);
-                    for (int m = 0; m < 3; ++m) v[m] -= t[m];
-                }
-                double t[3];
-                matvec3(q.Mi, v, t);
-                for (int m = 0; m < 3; ++m) rec[REC_T + 3 * e + m] = t[m];
-            }
+        double v[3];
+#define SDDP_COO(PA, PB) so2_coo_pair<PA, PB>(c, o, w, q, v); rec[REC_COO + 3 * (PA * (PA + 1) / 2 + PB)] = v[0]; \
+                         rec[REC_COO + 3 * (PA * (PA + 1) / 2 + PB) + 1] = v[1]; rec[REC_COO + 3 * (PA * (PA + 1) / 2 + PB) + 2] = v[2];
+        SDDP_COO(0, 0) SDDP_COO(1, 0) SDDP_COO(1, 1) SDDP_COO(2, 0) SDDP_COO(2, 1) SDDP_COO(2, 2)
+        SDDP_COO(3, 0) SDDP_COO(3, 1) SDDP_COO(3, 2) SDDP_COO(3, 3)
+#undef SDDP_COO
     }
 
     template <int QA>
@@ -942,15 +924,68 @@ struct SrbdModel {
                                                             int NZP, double theta, int lane, int nlanes) {
         if (SO2) {
             // full term (second_order = 2): Q += theta * (sum_m lam_m d2 wdot_m + dt v'_o . d2 odot), lam = dt v'_w + 2 gq wdot: the
-            // dynamics tensor contracted with v' plus the exact-minus-Gauss-Newton Hessian of the wdot rows of min_qddot
+            // dynamics tensor contracted with v' plus the exact-minus-Gauss-Newton Hessian of the wdot rows of min_qddot.
+            // lam . d_a d_b wdot = y . V_ab, y = I_w^-1 lam (so2_record), one lane per pair (a >= b) of compact columns:
+            //   f_i x (r | c_i):  +- s y . (e x e)                                       (the bilinear torque)
+            //   w x w:            -[(I_w e_b x y)_a + (I_w e_a x y)_b]                   (gyroscopic term)
+            //   w_a x o_b:        -[(dI_b w) x y + dI_b (y x w)]_a
+            //   o_a x o_b:        -y . c_ab
+            //   o_a x any b:      -(dI_a y) . A[:, b]      (and symmetrically for b in o)
             const double l0 = c.dt * vp[XW] + 2 * c.gq * rec[REC_WD], l1 = c.dt * vp[XW + 1] + 2 * c.gq * rec[REC_WD + 1],
                          l2 = c.dt * vp[XW + 2] + 2 * c.gq * rec[REC_WD + 2];
+            const double* Mi = rec + REC_MI;
+            const double y0 = Mi[0] * l0 + Mi[1] * l1 + Mi[2] * l2, y1 = Mi[3] * l0 + Mi[4] * l1 + Mi[5] * l2,
+                         y2 = Mi[6] * l0 + Mi[7] * l1 + Mi[8] * l2;
+            const double w0 = rec[REC_W], w1 = rec[REC_W + 1], w2 = rec[REC_W + 2];
+            auto sel = [](int i, double a0, double a1, double a2) { return i == 0 ? a0 : (i == 1 ? a1 : a2); };
+            // (dI_q y) . A[:, col]
+            auto g_dot_A = [&](int q, int col) {
+                const double* D = rec + REC_DM + 9 * q;
+                const double g0 = D[0] * y0 + D[1] * y1 + D[2] * y2, g1 = D[3] * y0 + D[4] * y1 + D[5] * y2,
+                             g2 = D[6] * y0 + D[7] * y1 + D[8] * y2;          // dI_q is symmetric
+                return g0 * rec[REC_A + col] + g1 * rec[REC_A + NA + col] + g2 * rec[REC_A + 2 * NA + col];
+            };
             for (int e = lane; e < NTRI; e += nlanes) {
                 int a = 0;
                 while ((a + 1) * (a + 2) / 2 <= e) ++a;
-                const int b = e - a * (a + 1) / 2;
-                const double* t = rec + REC_T + 3 * e;
-                double val = theta * (l0 * t[0] + l1 * t[1] + l2 * t[2]);
+                const int b = e - a * (a + 1) / 2;                  // a >= b
+                const bool ao = a >= 3 && a < 7, bo = b >= 3 && b < 7, aw = a >= 7 && a < 10, bw = b >= 7 && b < 10;
+                const bool af = a >= AF, br = b < 3, bc = CS && b >= AC && b < AF;
+                double sv = 0.0;
+                if (af && (br || bc)) {      // d2 n / (dc df) = s e_c x e_f, d2 n / (dr df) = -s e_r x e_f
+                    const int i = (a - AF) / 3, fa = (a - AF) % 3;
+                    const bool hit = br || (b - AC) / 3 == i;
+                    const int xa = br ? b : (b - AC) % 3;
+                    if (hit && xa != fa) {
+                        const int third = 3 - xa - fa;
+                        const double sg = ((fa - xa + 3) % 3 == 1) ? 1.0 : -1.0;       // (e_x x e_f)[third]
+                        sv = (br ? -c.lever : c.lever) * sg * sel(third, y0, y1, y2);
+                    }
+                } else if (aw && bw) {
+                    const int ia = a - 7, ib = b - 7;
+                    const double* Mm = rec + REC_M;
+                    // (m x y)_k = m_{k+1} y_{k+2} - m_{k+2} y_{k+1},  m = column of I_w
+                    auto cr = [&](int col, int k) {
+                        const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+                        return Mm[3 * k1 + col] * sel(k2, y0, y1, y2) - Mm[3 * k2 + col] * sel(k1, y0, y1, y2);
+                    };
+                    sv = -(cr(ib, ia) + cr(ia, ib));
+                } else if (aw && bo) {
+                    const double* D = rec + REC_DM + 9 * (b - 3);
+                    const double t0 = D[0] * w0 + D[1] * w1 + D[2] * w2, t1 = D[3] * w0 + D[4] * w1 + D[5] * w2,
+                                 t2 = D[6] * w0 + D[7] * w1 + D[8] * w2;                               // dI_b w
+                    const double z0 = y1 * w2 - y2 * w1, z1 = y2 * w0 - y0 * w2, z2 = y0 * w1 - y1 * w0;   // y x w
+                    const double h0 = (t1 * y2 - t2 * y1) + (D[0] * z0 + D[1] * z1 + D[2] * z2);
+                    const double h1 = (t2 * y0 - t0 * y2) + (D[3] * z0 + D[4] * z1 + D[5] * z2);
+                    const double h2 = (t0 * y1 - t1 * y0) + (D[6] * z0 + D[7] * z1 + D[8] * z2);
+                    sv = -sel(a - 7, h0, h1, h2);
+                } else if (ao && bo) {
+                    const double* cc = rec + REC_COO + 3 * ((a - 3) * (a - 2) / 2 + (b - 3));
+                    sv = -(y0 * cc[0] + y1 * cc[1] + y2 * cc[2]);
+                }
+                if (ao) sv -= g_dot_A(a - 3, b);
+                if (bo) sv -= g_dot_A(b - 3, a);
+                double val = theta * sv;
                 if (a >= 7 && a < 10 && b >= 3 && b < 7) {
                     // odot = 1/2 [w;0] (x) o is bilinear in (o, w): sum_q v'_o[q] d2 odot_q / do_b dw_c = 1/2 (+-) v'_o[.], from
                     // Jo (derivs(): rows q, columns b) = 1/2 [[0,-w2,w1,w0],[w2,0,-w0,w1],[-w1,w0,0,w2],[-w0,-w1,-w2,0]]

@@ -336,6 +336,34 @@ def test_closed_loop_walks_for_a_hundred_ticks():
         assert max(its[5:]) <= 8, (model, max(its))
 
 
+def test_closed_loop_tracking_holds_under_a_per_tick_iteration_budget():
+    """The real-time remedy for a slow tick (bench.py ms_per_fleet_tick.budgeted): at most `max_iters` DDP
+    iterations per tick, the unfinished iterate (status 1) is carried on as the next tick's warm start -- the solver object keeps
+    its previous solution (dsrbd_example.py:59).  Closed loop, walking at the commanded 0.5 m/s: the budgeted loop must track
+    like the loop that solves every tick to convergence."""
+    from srbd_horizon_amd.mpc import MpcLoop, EXAMPLE_OPTS
+    for model, ns, budget in (("srbd13", 30, 2), ("srbd37", 20, 2)):
+        full = MpcLoop(model, ns, warm_start="device")
+        bud = MpcLoop(model, ns, warm_start="device", opts=dict(EXAMPLE_OPTS, max_iters=budget))
+        xs_f, xs_b, unfinished, its = [], [], 0, []
+        for t in range(100):
+            full.tick("walking", (1.0, 0.0))
+            ok, _ = bud.tick("walking", (1.0, 0.0))
+            st = bud.solver.stats
+            assert int(st["iters"]) <= budget and int(st["status"]) in (0, 1)
+            unfinished += int(st["status"]) == 1
+            its.append(int(st["iters"]))
+            xs_f.append(full.state.copy()); xs_b.append(bud.state.copy())
+        xs_f, xs_b = np.array(xs_f), np.array(xs_b)
+        assert unfinished >= 5, (model, unfinished)                                   # the budget did bind
+        v = (xs_b[-1, 0] - xs_b[39, 0]) / (60 * 0.05)                                 # mean forward velocity over the last 3 s
+        assert 0.3 < v < 0.6, (model, v)
+        assert abs(xs_b[-1, 1]) < 0.1 and 0.8 < xs_b[-1, 2] < 1.1, (model, xs_b[-1, :3])
+        dev = np.max(np.abs(xs_b[:, 0:3] - xs_f[:, 0:3]))                             # CoM path against the converged loop
+        print(f"{model}: budget {budget} iterations/tick, {unfinished} of 100 ticks unfinished, CoM deviation from the converged loop {dev:.2e} m")
+        assert dev < 0.02, (model, dev)
+
+
 def test_whole_bench_batch_matches_the_c_oracle():
     """All 1024 instances of the bench batch (BASELINE configs[2]) against the plain-C restatement of the oracle
     (oracle/c, pinned to the numpy oracle by tests/test_oracle_c.py): same iteration count and, at the north_star tolerance
