@@ -238,7 +238,7 @@ def main():
     acc += fleet.si[:1, 10].sum()                              # (first use of these device ops is never inside the timed region)
     acc.zero_()
     barrier()
-    l0 = fleet.launches
+    l0, g0 = fleet.launches, fleet.gather_bytes
     elapsed = timed(fleet, d_t, steps, count=True)
     if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -275,7 +275,7 @@ def main():
                                    "block": f"seeds b*{B} .. b*{B}+{B - 1}"},
                    "collective": "asynchronous double-buffered all_gather(solution records) per launch, waited for inside the timed region"
                                  if collective else "none",
-                   "gather_bytes_per_launch_per_rank": (fleet.gather_bytes // max(fleet.launches, 1)) if collective else 0},
+                   "gather_bytes_per_launch_per_rank": ((fleet.gather_bytes - g0) // max(launches, 1)) if collective else 0},
         "mean_iters": tot_iters / n_solves, "mean_rollouts": tot_roll / n_solves,
         "last_launch": {"instances": int(n_last), "mean_iters": float(np.mean(iters)), "max_iters": int(np.max(iters)),
                         "max_iters_hit_frac": float(np.mean(st["status"] == 1)), "converged_frac": float(np.mean(st["converged"] == 1)),
