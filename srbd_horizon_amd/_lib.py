@@ -103,7 +103,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, "-I" + CSRC,
+    extra = os.environ.get("SDDP_CXXFLAGS", "").split()      # diagnostic builds only (-DSDDP_NO_MFMA, -DSDDP_STAMPS), with SDDP_LIB
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, "-I" + CSRC, *extra,
            src, sort_src, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
