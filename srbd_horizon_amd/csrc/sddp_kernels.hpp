@@ -115,7 +115,8 @@ struct Lds {
     static constexpr int NZP = (NZ + 3) & ~3;
     static constexpr int SQ = (NZP % 4 == 0) ? NZP + 2 : NZP;          // row stride of the Q tile: == 2 (mod 4) as well
     static constexpr int NUP = (NU + 1) & ~1;
-    static constexpr int NRECP = (M::NREC + 1) & ~1;
+    static constexpr int NRECP = (((M::NREC + 1) & ~1) + M::NSO2T + 1) & ~1;   // record, then the second-order factors (SO2 builds)
+    static constexpr int SO2T = (M::NREC + 1) & ~1;                             // ... at this offset from REC
     static constexpr int NPP = (M::NP + 1) & ~1;
     static constexpr int VXX = 0;
     static constexpr int FT = VXX + NXP * NXP;
@@ -139,7 +140,8 @@ struct Lds {
     static constexpr int NBQ = NZP / 2, NTRIQ = NBQ * (NBQ + 1) / 2;
     static constexpr int ntriv(int nx) { int n = 0; for (int a = 0; a < nx; ++a) n += a / 2 + 1; return n; }
     static constexpr int NTRIV = ntriv(NX);        // Vxx update: 1 x 2 blocks (row a, column pair 2bp, 2bp+1 with 2bp <= a)
-    static constexpr int KI_INTS = 2 * NZP + NTRIQ + NTRIV;
+    static constexpr int SO2L = 2 * NZP + NTRIQ + NTRIV;       // SO2 builds: pair codes of the second-order contraction
+    static constexpr int KI_INTS = SO2L + M::NSO2L;
     static constexpr int RO = KI + (KI_INTS + 1) / 2;  // rollout staging: xs | us | p | gains | dft of one knot
     static constexpr int RO_X = 0, RO_U = NXP, RO_P = RO_U + NUP, RO_G = RO_P + NPP, RO_D = RO_G + ((NU * (NX + 1) + 1) & ~1);
     static constexpr int RO_N = RO_D + NXP;
@@ -242,6 +244,7 @@ __device__ void sweep_tables(const DevConsts& c, double* s, int lane) {
         while (first + a / 2 + 1 <= t) { first += a / 2 + 1; ++a; }
         ki[2 * L::NZP + L::NTRIQ + t] = (a << 8) | (t - first);
     }
+    for (int e = lane; e < M::NSO2L / 2; e += kWave) M::so2_pair_code(e, ki[L::SO2L + 2 * e], ki[L::SO2L + 2 * e + 1]);
     wave_sync();
 }
 
@@ -501,7 +504,11 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         }
         wave_sync();
         if (theta != 0.0) {   // exact second-order torque term (wave-uniform switch)
-            M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, SQ, theta, lane, kWave);
+            if (M::NSO2T) {   // full second-order builds: the per-knot factors of the contraction first
+                M::so2_prepare(c, s + L::REC, s + L::VP, s + L::REC + L::SO2T, lane, kWave);
+                wave_sync();
+            }
+            M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, SQ, theta, lane, kWave, s + L::REC + L::SO2T, ki + L::SO2L);
             wave_sync();
         }
         if (M::BAR) {         // friction-cone barrier builds: its Hessian blocks on the force-force diagonal of Q

@@ -44,7 +44,8 @@ struct LdsMW {
     static constexpr int SK = pad2mod4(NU);                                     // KT [NX][SK]: KT[c][i] = K[i][c]
     static constexpr int RPW = (NU + kWavesMW - 1) / kWavesMW;                  // Gauss-Jordan rows per wave
     static constexpr int NSTG = M::NREC + M::NP + NX;                           // staged knot: record | params | defect
-    static constexpr int NRECP = (M::NREC + 1) & ~1, NPP = (M::NP + 1) & ~1;
+    static constexpr int NRECP = (((M::NREC + 1) & ~1) + M::NSO2T + 1) & ~1, NPP = (M::NP + 1) & ~1;   // record + second-order factors (SO2)
+    static constexpr int SO2T = (M::NREC + 1) & ~1;
     static constexpr int SG = (NX + 1) & ~1;                                    // staged gain rows in the forward pass
     static constexpr int VXX = 0;
     static constexpr int FT = VXX + RV * SV;
@@ -63,7 +64,8 @@ struct LdsMW {
     static constexpr int LG = LS + ((NE + 1) & ~1);
     static constexpr int CTL = LG + ((NE + 1) & ~1);   // control words shared by the 4 waves [16]
     static constexpr int KI = CTL + 16;                // ints: dkind[SQ], dci[SQ], block LUTs of Q and Vxx
-    static constexpr int KI_INTS = 2 * SQ + NTRIQ + NTRIV;
+    static constexpr int SO2L = 2 * SQ + NTRIQ + NTRIV;          // SO2 builds: pair codes of the second-order contraction
+    static constexpr int KI_INTS = SO2L + M::NSO2L;
     static constexpr int WT = KI + ((KI_INTS + 1) / 2 + 1) / 2 * 2;
     static constexpr int Q = WT + RZ * SI;
     // forward pass: per-lane vector columns X | Y | U and the staged gains of one knot alias WT and Q (and may run past Q)
@@ -155,6 +157,7 @@ __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
         while ((a + 1) * (a + 2) / 2 <= tt) ++a;
         ki[2 * L::SQ + t] = (a << 8) | (tt - a * (a + 1) / 2);
     }
+    for (int e = tid; e < M::NSO2L / 2; e += kThreadsMW) M::so2_pair_code(e, ki[L::SO2L + 2 * e], ki[L::SO2L + 2 * e + 1]);
     __syncthreads();
 }
 
@@ -318,7 +321,12 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         __syncthreads();
         SDDP_TICK(14)
         if (theta != 0.0) {   // exact second-order torque term (uniform switch)
-            M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, SQ, theta, tid, kThreadsMW);
+            if (M::NSO2T) {   // full second-order builds: the per-knot factors of the contraction first
+                M::so2_prepare(c, s + L::REC, s + L::VP, s + L::REC + L::SO2T, tid, kThreadsMW);
+                __syncthreads();
+            }
+            M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, SQ, theta, tid, kThreadsMW, s + L::REC + L::SO2T,
+                                reinterpret_cast<const int*>(s + L::KI) + L::SO2L);
             __syncthreads();
         }
         if (M::BAR) {         // friction-cone barrier builds: its Hessian blocks on the force-force diagonal of Q

@@ -244,7 +244,12 @@ struct SrbdModel {
                          REC_COO = REC_DM + 36,                    //   w x (d2I_w/do_a do_b w) + d2I_w/do_a do_b wdot for the 10
                          REC_W = REC_COO + 30,                     //   pairs a >= b (10 x 3) | w (3)
                          NTRI = NA * (NA + 1) / 2,
-                         NREC = SO2 ? REC_W + 3 : REC_WD;
+                         NREC = SO2 ? REC_W + 3 : REC_WD,
+                         // SO2: per-knot factors of the contraction, computed once per knot in LDS (so2_prepare): y (3) | dI_a y
+                         // (4 x 3) | h_b = (dI_b w) x y + dI_b (y x w) (4 x 3) | P[a][b] = (I_w e_b x y)_a (9) | y . c_ab (10)
+                         //   then two zero words (the slot of "no term")
+                         T_Y = 0, T_G = 3, T_H = 15, T_P = 27, T_D = 36, T_ZERO = 46, NSO2T = SO2 ? 48 : 0,
+                         NSO2L = SO2 ? 2 * NTRI : 0;       // ints: pair codes of the contraction (so2_pair_code), built once per instance
 
     __device__ __forceinline__ static int uf(int i) { return CS ? 6 * i + 3 : 3 * i; }  // prb.py:66-68 interleaved
     // parameter layouts: srbd37 = creation order; srbd13 = App. A.7
@@ -920,92 +925,131 @@ struct SrbdModel {
     //   Qux[f_i,a][r_b] += -theta * s * skew(y)[a][b] ,  Qux[f_i,a][c_i,b] += +theta * s * skew(y)[a][b] ,  y = I_w^-1 (dt v'_w)
     // (constant tensor; Q is kept symmetric: both triangles are updated)
     static constexpr int NSO = 9 * NC * (CS ? 2 : 1);
-    __device__ __forceinline__ static void add_second_order(const DevConsts& c, const double* rec, const double* vp, double* Q,
-                                                            int NZP, double theta, int lane, int nlanes) {
-        if (SO2) {
-            // full term (second_order = 2): Q += theta * (sum_m lam_m d2 wdot_m + dt v'_o . d2 odot), lam = dt v'_w + 2 gq wdot: the
-            // dynamics tensor contracted with v' plus the exact-minus-Gauss-Newton Hessian of the wdot rows of min_qddot.
-            // lam . d_a d_b wdot = y . V_ab, y = I_w^-1 lam (so2_record), one lane per pair (a >= b) of compact columns:
-            //   f_i x (r | c_i):  +- s y . (e x e)                                       (the bilinear torque)
-            //   w x w:            -[(I_w e_b x y)_a + (I_w e_a x y)_b]                   (gyroscopic term)
-            //   w_a x o_b:        -[(dI_b w) x y + dI_b (y x w)]_a
-            //   o_a x o_b:        -y . c_ab
-            //   o_a x any b:      -(dI_a y) . A[:, b]      (and symmetrically for b in o)
+    // SO2 builds: the 46 per-knot factors of the second-order contraction (layout T_*), one per lane, into `tmp` (LDS); the
+    // caller synchronises before add_second_order reads them.  lam = dt v'_w + 2 gq wdot, y = I_w^-1 lam.
+    __device__ __forceinline__ static void so2_prepare(const DevConsts& c, const double* rec, const double* vp, double* tmp, int lane,
+                                                       int nlanes) {
+        if (!SO2) return;
+        for (int t = lane; t < NSO2T; t += nlanes) {
+            if (t >= T_ZERO) { tmp[t] = 0.0; continue; }
             const double l0 = c.dt * vp[XW] + 2 * c.gq * rec[REC_WD], l1 = c.dt * vp[XW + 1] + 2 * c.gq * rec[REC_WD + 1],
                          l2 = c.dt * vp[XW + 2] + 2 * c.gq * rec[REC_WD + 2];
             const double* Mi = rec + REC_MI;
             const double y0 = Mi[0] * l0 + Mi[1] * l1 + Mi[2] * l2, y1 = Mi[3] * l0 + Mi[4] * l1 + Mi[5] * l2,
                          y2 = Mi[6] * l0 + Mi[7] * l1 + Mi[8] * l2;
-            const double w0 = rec[REC_W], w1 = rec[REC_W + 1], w2 = rec[REC_W + 2];
             auto sel = [](int i, double a0, double a1, double a2) { return i == 0 ? a0 : (i == 1 ? a1 : a2); };
-            // (dI_q y) . A[:, col]
-            auto g_dot_A = [&](int q, int col) {
-                const double* D = rec + REC_DM + 9 * q;
-                const double g0 = D[0] * y0 + D[1] * y1 + D[2] * y2, g1 = D[3] * y0 + D[4] * y1 + D[5] * y2,
-                             g2 = D[6] * y0 + D[7] * y1 + D[8] * y2;          // dI_q is symmetric
-                return g0 * rec[REC_A + col] + g1 * rec[REC_A + NA + col] + g2 * rec[REC_A + 2 * NA + col];
-            };
+            double v;
+            if (t < T_G) {
+                v = sel(t, y0, y1, y2);
+            } else if (t < T_H) {                      // (dI_a y)_m
+                const double* D = rec + REC_DM + 9 * ((t - T_G) / 3) + 3 * ((t - T_G) % 3);
+                v = D[0] * y0 + D[1] * y1 + D[2] * y2;
+            } else if (t < T_P) {                      // h_b[m] = ((dI_b w) x y + dI_b (y x w))_m
+                const double* D = rec + REC_DM + 9 * ((t - T_H) / 3);
+                const int m = (t - T_H) % 3;
+                const double w0 = rec[REC_W], w1 = rec[REC_W + 1], w2 = rec[REC_W + 2];
+                const double t0 = D[0] * w0 + D[1] * w1 + D[2] * w2, t1 = D[3] * w0 + D[4] * w1 + D[5] * w2,
+                             t2 = D[6] * w0 + D[7] * w1 + D[8] * w2;
+                const double z0 = y1 * w2 - y2 * w1, z1 = y2 * w0 - y0 * w2, z2 = y0 * w1 - y1 * w0;
+                const double cr = sel(m, t1 * y2 - t2 * y1, t2 * y0 - t0 * y2, t0 * y1 - t1 * y0);
+                v = cr + D[3 * m] * z0 + D[3 * m + 1] * z1 + D[3 * m + 2] * z2;
+            } else if (t < T_D) {                      // P[a][b] = (I_w e_b x y)_a = m_{a+1} y_{a+2} - m_{a+2} y_{a+1}, m = column b
+                const int a = (t - T_P) / 3, b = (t - T_P) % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+                v = rec[REC_M + 3 * a1 + b] * sel(a2, y0, y1, y2) - rec[REC_M + 3 * a2 + b] * sel(a1, y0, y1, y2);
+            } else {                                   // y . c_pair
+                const double* cc = rec + REC_COO + 3 * (t - T_D);
+                v = y0 * cc[0] + y1 * cc[1] + y2 * cc[2];
+            }
+            tmp[t] = v;
+        }
+    }
+
+    // Pair e = a (a + 1) / 2 + b (a >= b) of compact columns -> two ints that make the per-knot contraction branch-free:
+    //   w0: row | col << 8 | i1 << 16 | i2 << 24     z indices of the Q entry; tmp slots of the two direct terms (T_ZERO: none)
+    //   w1: qa | colb << 2 | m1 << 9 | qb << 10 | cola << 12 | m2 << 19 | qo << 20 | so << 22 | c1 << 24 | bar << 26
+    //       -(dI_qa y) . A[:, colb] if m1, -(dI_qb y) . A[:, cola] if m2; quaternion-rate term so (1: +, 2: -) * v'_o[qo];
+    //       c1: coefficient of the first direct term (0: -1, 1: +lever, 2: -lever); the second one is -1;
+    //       bar: i2 holds contact << 4 | fa << 2 | fb of a barrier block instead of a tmp slot.
+    // Built once per instance into LDS (sweep tables); the class logic is the one of oracle/models.py srbd_wdot_hess.
+    __device__ __forceinline__ static void so2_pair_code(int e, int& w0, int& w1) {
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= e) ++a;
+        const int b = e - a * (a + 1) / 2;
+        const bool ao = a >= 3 && a < 7, bo = b >= 3 && b < 7, aw = a >= 7 && a < 10, bw = b >= 7 && b < 10;
+        const bool af = a >= AF, br = b < 3, bc = CS && b >= AC && b < AF;
+        int i1 = T_ZERO, i2 = T_ZERO, c1 = 0, bar = 0, so = 0, qo = 0;
+        if (af && (br || bc)) {          // d2 n / (dc df) = s e_c x e_f, d2 n / (dr df) = -s e_r x e_f
+            const int i = (a - AF) / 3, fa = (a - AF) % 3;
+            const bool hit = br || (b - AC) / 3 == i;
+            const int xa = br ? b : (b - AC) % 3;
+            if (hit && xa != fa) {
+                const bool pos = ((fa - xa + 3) % 3 == 1);                 // (e_x x e_f)[third] = +1
+                i1 = T_Y + (3 - xa - fa);
+                c1 = (pos != br) ? 1 : 2;                                  // (br ? -lever : lever) * (pos ? 1 : -1)
+            }
+        } else if (aw && bw) {
+            i1 = T_P + 3 * (a - 7) + (b - 7);
+            i2 = T_P + 3 * (b - 7) + (a - 7);
+        } else if (aw && bo) {
+            i1 = T_H + 3 * (b - 3) + (a - 7);
+            // quaternion rate: sum_q v'_o[q] d2 odot_q / do_b dw_c = 1/2 (+-) v'_o[q] for exactly one q
+            const int ob = b - 3, cc = a - 7;
+            for (int q = 0; q < 4; ++q) {
+                if (q == ob) continue;
+                int comp; bool plus;
+                if (q == 3) { comp = ob; plus = false; }
+                else if (ob == 3) { comp = q; plus = true; }
+                else { comp = 3 - q - ob; plus = !((ob - q + 3) % 3 == 1); }
+                if (comp == cc) { qo = q; so = plus ? 1 : 2; }
+            }
+        } else if (ao && bo) {
+            i1 = T_D + (a - 3) * (a - 2) / 2 + (b - 3);
+        }
+        if (BAR && a >= AF && b >= AF && (a - AF) / 3 == (b - AF) / 3) {
+            bar = 1;
+            i2 = (((a - AF) / 3) << 4) | (((a - AF) % 3) << 2) | ((b - AF) % 3);
+        }
+        w0 = zcol(a) | (zcol(b) << 8) | (i1 << 16) | (i2 << 24);
+        w1 = (ao ? a - 3 : 0) | (b << 2) | ((ao ? 1 : 0) << 9) | ((bo ? b - 3 : 0) << 10) | (a << 12) | ((bo ? 1 : 0) << 19) | (qo << 20) |
+             (so << 22) | (c1 << 24) | (bar << 26);
+    }
+
+    __device__ __forceinline__ static void add_second_order(const DevConsts& c, const double* rec, const double* vp, double* Q,
+                                                            int NZP, double theta, int lane, int nlanes, const double* tmp = nullptr,
+                                                            const int* lut = nullptr) {
+        if (SO2) {
+            // full term (second_order = 2): Q += theta * (sum_m lam_m d2 wdot_m + dt v'_o . d2 odot), lam = dt v'_w + 2 gq wdot: the
+            // dynamics tensor contracted with v' plus the exact-minus-Gauss-Newton Hessian of the wdot rows of min_qddot.
+            // lam . d_a d_b wdot = y . V_ab, y = I_w^-1 lam (so2_record): one lane per pair (a >= b) of compact columns, from the
+            // per-knot factors of so2_prepare (tmp) and the pair codes (lut), every operand requested before the first use:
+            //   f_i x (r | c_i):  +- s y . (e x e)                                       (the bilinear torque)
+            //   w x w:            -(P[a][b] + P[b][a]),  P[a][b] = (I_w e_b x y)_a        (gyroscopic term)
+            //   w_a x o_b:        -h_b[a],  h_b = (dI_b w) x y + dI_b (y x w)
+            //   o_a x o_b:        -y . c_ab
+            //   o_a x any b:      -(dI_a y) . A[:, b]      (and symmetrically for b in o)
             for (int e = lane; e < NTRI; e += nlanes) {
-                int a = 0;
-                while ((a + 1) * (a + 2) / 2 <= e) ++a;
-                const int b = e - a * (a + 1) / 2;                  // a >= b
-                const bool ao = a >= 3 && a < 7, bo = b >= 3 && b < 7, aw = a >= 7 && a < 10, bw = b >= 7 && b < 10;
-                const bool af = a >= AF, br = b < 3, bc = CS && b >= AC && b < AF;
-                double sv = 0.0;
-                if (af && (br || bc)) {      // d2 n / (dc df) = s e_c x e_f, d2 n / (dr df) = -s e_r x e_f
-                    const int i = (a - AF) / 3, fa = (a - AF) % 3;
-                    const bool hit = br || (b - AC) / 3 == i;
-                    const int xa = br ? b : (b - AC) % 3;
-                    if (hit && xa != fa) {
-                        const int third = 3 - xa - fa;
-                        const double sg = ((fa - xa + 3) % 3 == 1) ? 1.0 : -1.0;       // (e_x x e_f)[third]
-                        sv = (br ? -c.lever : c.lever) * sg * sel(third, y0, y1, y2);
-                    }
-                } else if (aw && bw) {
-                    const int ia = a - 7, ib = b - 7;
-                    const double* Mm = rec + REC_M;
-                    // (m x y)_k = m_{k+1} y_{k+2} - m_{k+2} y_{k+1},  m = column of I_w
-                    auto cr = [&](int col, int k) {
-                        const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-                        return Mm[3 * k1 + col] * sel(k2, y0, y1, y2) - Mm[3 * k2 + col] * sel(k1, y0, y1, y2);
-                    };
-                    sv = -(cr(ib, ia) + cr(ia, ib));
-                } else if (aw && bo) {
-                    const double* D = rec + REC_DM + 9 * (b - 3);
-                    const double t0 = D[0] * w0 + D[1] * w1 + D[2] * w2, t1 = D[3] * w0 + D[4] * w1 + D[5] * w2,
-                                 t2 = D[6] * w0 + D[7] * w1 + D[8] * w2;                               // dI_b w
-                    const double z0 = y1 * w2 - y2 * w1, z1 = y2 * w0 - y0 * w2, z2 = y0 * w1 - y1 * w0;   // y x w
-                    const double h0 = (t1 * y2 - t2 * y1) + (D[0] * z0 + D[1] * z1 + D[2] * z2);
-                    const double h1 = (t2 * y0 - t0 * y2) + (D[3] * z0 + D[4] * z1 + D[5] * z2);
-                    const double h2 = (t0 * y1 - t1 * y0) + (D[6] * z0 + D[7] * z1 + D[8] * z2);
-                    sv = -sel(a - 7, h0, h1, h2);
-                } else if (ao && bo) {
-                    const double* cc = rec + REC_COO + 3 * ((a - 3) * (a - 2) / 2 + (b - 3));
-                    sv = -(y0 * cc[0] + y1 * cc[1] + y2 * cc[2]);
-                }
-                if (ao) sv -= g_dot_A(a - 3, b);
-                if (bo) sv -= g_dot_A(b - 3, a);
-                double val = theta * sv;
-                if (a >= 7 && a < 10 && b >= 3 && b < 7) {
-                    // odot = 1/2 [w;0] (x) o is bilinear in (o, w): sum_q v'_o[q] d2 odot_q / do_b dw_c = 1/2 (+-) v'_o[.], from
-                    // Jo (derivs(): rows q, columns b) = 1/2 [[0,-w2,w1,w0],[w2,0,-w0,w1],[-w1,w0,0,w2],[-w0,-w1,-w2,0]]
-                    const int ob = b - 3, cc = a - 7;
-                    double v = 0.0;
-                    for (int q = 0; q < 4; ++q) {
-                        if (q == ob) continue;
-                        int comp; double sg;
-                        if (q == 3) { comp = ob; sg = -1.0; }
-                        else if (ob == 3) { comp = q; sg = 1.0; }
-                        else { comp = 3 - q - ob; sg = ((ob - q + 3) % 3 == 1) ? -1.0 : 1.0; }
-                        if (comp == cc) v += sg * vp[XO + q];
-                    }
-                    val += 0.5 * theta * c.dt * v;
-                }
-                if (BAR && a >= AF && b >= AF && (a - AF) / 3 == (b - AF) / 3)   // barrier: exact - Gauss-Newton Hessian = its GN block once more
-                    val += theta * barrier_h(rec + REC_B + 5 * ((a - AF) / 3), (a - AF) % 3, (b - AF) % 3);
-                const int row = zcol(a), col = zcol(b);
-                Q[row * NZP + col] += val;
-                if (a != b) Q[col * NZP + row] += val;
+                const int w0 = lut[2 * e], w1 = lut[2 * e + 1];
+                const int row = w0 & 255, col = (w0 >> 8) & 255, i1 = (w0 >> 16) & 255, i2f = (w0 >> 24) & 255;
+                const int qa = w1 & 3, colb = (w1 >> 2) & 127, qb = (w1 >> 10) & 3, cola = (w1 >> 12) & 127, qo = (w1 >> 20) & 3;
+                const int so = (w1 >> 22) & 3, c1 = (w1 >> 24) & 3;
+                const bool m1 = (w1 >> 9) & 1, m2 = (w1 >> 19) & 1, bar = BAR && ((w1 >> 26) & 1);
+                const int i2 = bar ? int(T_ZERO) : i2f;
+                const double t1 = tmp[i1], t2 = tmp[i2], vo = vp[XO + qo];
+                const double* g1 = tmp + T_G + 3 * qa;
+                const double* g2 = tmp + T_G + 3 * qb;
+                const double g10 = g1[0], g11 = g1[1], g12 = g1[2], g20 = g2[0], g21 = g2[1], g22 = g2[2];
+                const double a10 = rec[REC_A + colb], a11 = rec[REC_A + NA + colb], a12 = rec[REC_A + 2 * NA + colb];
+                const double a20 = rec[REC_A + cola], a21 = rec[REC_A + NA + cola], a22 = rec[REC_A + 2 * NA + cola];
+                double q0 = Q[row * NZP + col];
+                const double cf = c1 == 0 ? -1.0 : (c1 == 1 ? c.lever : -c.lever);
+                double sv = cf * t1 - t2;
+                sv -= m1 ? (g10 * a10 + g11 * a11 + g12 * a12) : 0.0;
+                sv -= m2 ? (g20 * a20 + g21 * a21 + g22 * a22) : 0.0;
+                double val = theta * sv + (so == 0 ? 0.0 : (so == 1 ? 0.5 : -0.5) * theta * c.dt * vo);
+                if (bar) val += theta * barrier_h(rec + REC_B + 5 * (i2f >> 4), (i2f >> 2) & 3, i2f & 3);
+                q0 += val;
+                Q[row * NZP + col] = q0;
+                if (row != col) Q[col * NZP + row] = q0;     // Q is symmetric here: both triangles hold the same value
             }
             return;
         }
@@ -1049,7 +1093,9 @@ struct LipModel {
     __device__ __forceinline__ static void add_barrier(const double*, double*, int, int, int) {}
     static constexpr int NX = 30, NU = 15, NZ = 45, NP = 11;
     static constexpr int XR = 0, XC = 3, XRD = 15, XCD = 18;
-    static constexpr int REC_G = 0, NREC = NZ;
+    static constexpr int REC_G = 0, NREC = NZ, NSO2T = 0, NSO2L = 0;
+    __device__ __forceinline__ static void so2_prepare(const DevConsts&, const double*, const double*, double*, int, int) {}
+    __device__ __forceinline__ static void so2_pair_code(int, int&, int&) {}
     __device__ __forceinline__ static double p_cref(const double* p, int i) { return p[3 + 2 * i]; }
     __device__ __forceinline__ static double p_sw(const double* p, int i) { return p[4 + 2 * i]; }
 
@@ -1310,7 +1356,8 @@ struct LipModel {
     __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int) {}
     __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int, int, double* = nullptr,
                                                       const double* = nullptr) {}
-    __device__ __forceinline__ static void add_second_order(const DevConsts&, const double*, const double*, double*, int, double, int, int) {}
+    __device__ __forceinline__ static void add_second_order(const DevConsts&, const double*, const double*, double*, int, double, int, int,
+                                                            const double* = nullptr, const int* = nullptr) {}
 
 };
 
