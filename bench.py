@@ -182,9 +182,9 @@ def main():
     wps = args.waves_per_simd
 
     # every step solves its OWN instances: timed step i of this rank = seed block rank*steps + i, warm-up steps = other blocks
-    def load_blocks(blocks):
+    def load_blocks(blocks, x0_draw=0):
         seeds = np.concatenate([b * B + np.arange(B) for b in blocks])
-        h = workload.make_batch("srbd13", N, seeds)
+        h = workload.make_srbd13_batch(N, seeds, x0_draw=x0_draw)
         return {k: torch.from_numpy(h[k]).to(dev).reshape((len(blocks), B) + h[k].shape[1:]) for k in ("x0", "xs", "us", "params")}
 
     timed_blocks = [seed_block(rank, world, steps, warmup, "timed", i) for i in range(steps)]
@@ -299,6 +299,13 @@ def main():
         # the same instances in plain index order and (as a REPLAY: the handle has solved these very instances once before, so
         # the history is exact foreknowledge -- what a fleet of recurring robots approaches, not a cold-start figure) longest
         # previous solve first
+        # history order as a recurring fleet would see it: the handle has solved the same ROBOTS before (same schedule, command and
+        # footsteps) from another draw of the initial-state perturbation -- a similar problem, not the same one
+        e_o, f_o = make_queue(1)
+        d_sim = load_blocks(timed_blocks[:n_x], x0_draw=1)
+        run_steps(f_o, d_sim, n_x)
+        out["history_order_similar_problems_solves_per_s"] = B * n_x / timed(f_o, d_t, n_x)
+        del f_o, e_o, d_sim
         for order, key in ((0, "index_order_solves_per_s"), (1, "replay_history_order_solves_per_s"), (2, "initial_cost_order_solves_per_s")):
             if order == args.queue_order:
                 continue

@@ -56,8 +56,10 @@ def _closed_form(N, seeds, init_z, init_sw, init_otg):
     return z, sw, otg, n_td
 
 
-def make_srbd13_batch(N: int, seeds, robot: RobotModel | None = None):
-    """-> dict(x0 [B,13], params [B,N+1,19], xs [B,N+1,13], us [B,N,6], consts) for the metric model."""
+def make_srbd13_batch(N: int, seeds, robot: RobotModel | None = None, x0_draw: int = 0):
+    """-> dict(x0 [B,13], params [B,N+1,19], xs [B,N+1,13], us [B,N,6], consts) for the metric model.
+    x0_draw != 0: the same robots (schedule, velocity command, footsteps) with ANOTHER draw of the initial-state perturbation:
+    a robot's next problem, similar to its last one but not the same (bench.py: what a history-ordered queue sees)."""
     robot = robot or RobotModel()
     seeds = np.asarray(seeds, dtype=np.int64)
     B = seeds.shape[0]
@@ -78,7 +80,7 @@ def make_srbd13_batch(N: int, seeds, robot: RobotModel | None = None):
         P[:, :, 17 + leg] = sw[:, leg, :]
     x0 = np.tile(pb.getInitialState(), (B, 1))
     for b, s in enumerate(seeds):
-        rng = np.random.default_rng(int(s) + 1_000_003)
+        rng = np.random.default_rng(int(s) + 1_000_003 + 7_919 * int(x0_draw))
         x0[b, 0:3] += 0.01 * rng.standard_normal(3)
         dq = 0.02 * rng.standard_normal(3)
         q = np.array([dq[0], dq[1], dq[2], 1.0])
