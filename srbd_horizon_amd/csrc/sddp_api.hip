@@ -407,8 +407,10 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     h->own_stream = (e == hipSuccess);
     if (e == hipSuccess) e = alloc((void**)&h->x0, size_t(batch) * d.nx * D);
     if (e == hipSuccess) e = alloc((void**)&h->P, h->n_p() * D);
-    if (e == hipSuccess) e = alloc((void**)&h->xs, h->n_x() * D);
-    if (e == hipSuccess) e = alloc((void**)&h->us, h->n_u() * D);
+    // xs | us | stats in ONE allocation: the results of a solve leave the device in one copy (a tick of one robot is three API
+    // calls shorter)
+    if (e == hipSuccess) e = alloc((void**)&h->xs, (h->n_x() + h->n_u()) * D + size_t(batch) * sizeof(sddp_stats));
+    if (e == hipSuccess) { h->us = h->xs + h->n_x(); h->stats = reinterpret_cast<sddp_stats*>(h->us + h->n_u()); }
     if (e == hipSuccess) e = alloc((void**)&h->xn, W * (N + 1) * d.nx * D);
     if (e == hipSuccess) e = alloc((void**)&h->un, W * N * d.nu * D);
     if (!model_uses_mw(model_id)) {   // one-wave kernel: two sets of kSlots line-search candidates per slot
@@ -419,7 +421,6 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (e == hipSuccess) e = alloc((void**)&h->gains, W * N * d.nu * (d.nx + 1) * D);
     if (e == hipSuccess) e = alloc((void**)&h->rec, W * (N + 1) * d.nrec * D);
     if (e == hipSuccess) e = alloc((void**)&h->scal, size_t(batch) * kScal * D);
-    if (e == hipSuccess) e = alloc((void**)&h->stats, size_t(batch) * sizeof(sddp_stats));
     if (e == hipSuccess) e = alloc((void**)&h->qhead, sizeof(int));
     if (e == hipSuccess) e = alloc((void**)&h->order, size_t(batch) * sizeof(int));
     if (e == hipSuccess) e = alloc((void**)&h->hist, size_t(batch) * sizeof(int));
@@ -444,7 +445,7 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
 void sddp_destroy(sddp_handle* h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->x0, h->P, h->xs, h->us, h->xn, h->un, h->xc, h->uc, h->tick_in, h->step_buf, h->dft, h->gains, h->rec, h->scal, h->stats,
+    void* bufs[] = {h->x0, h->P, h->xs /* | us | stats */, h->xn, h->un, h->xc, h->uc, h->tick_in, h->step_buf, h->dft, h->gains, h->rec, h->scal,
                     h->qhead, h->order, h->hist, h->qkey, h->qkey2, h->order_in, h->sort_tmp};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -606,9 +607,7 @@ static int fetch_results(sddp_handle* h, double* x_out, double* u_out, sddp_stat
     }
     if (h->pinned && h->pinned_bytes >= bx + bu + bs) {
         char* st = static_cast<char*>(h->pinned);
-        HIP_TRY(h, hipMemcpyAsync(st, h->xs, bx, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(st + bx, h->us, bu, hipMemcpyDeviceToHost, h->stream));
-        if (stats) HIP_TRY(h, hipMemcpyAsync(st + bx + bu, h->stats, bs, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(st, h->xs, bx + bu + (stats ? bs : 0), hipMemcpyDeviceToHost, h->stream));   // xs | us | stats are contiguous
         const int rc = sddp_synchronize(h);
         if (rc != SDDP_OK) return rc;
         std::memcpy(x_out, st, bx);

@@ -47,3 +47,25 @@ def test_no_timed_instance_is_solved_before_the_timed_region():
     src = open(bench.__file__).read()
     assert '"--queue-order", type=int, default=2' in src              # `value` = largest initial cost first: no history
     assert "replay_history_order_solves_per_s" in src                 # the foreknowledge figure is an extra, named as a replay
+
+
+def test_queue_model_reproduces_the_design_table():
+    """tools/queue_sim.py is the list-scheduling model DESIGN.md section 5 quotes (queue orders, instances per wavefront): its
+    data file and its conclusions are pinned here so that the table stays reproducible."""
+    spec = importlib.util.spec_from_file_location("queue_sim", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "queue_sim.py"))
+    qs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(qs)
+    d = np.load(os.path.join(os.path.dirname(qs.__file__), "data", "bench_queue_iters.npz"))
+    it, rank = d["iters"].astype(int), d["j0_rank"]
+    assert len(it) == 20480 and it.max() == 100 and abs(it.mean() - 16.30) < 0.01
+    index, cost, exact = np.arange(len(it)), np.argsort(rank), np.argsort(-it, kind="stable")
+    m = {(name, G): qs.simulate(it, order, G) for name, order in (("index", index), ("cost", cost), ("exact", exact)) for G in (1, 2, 4)}
+    ideal = float(np.sum(it * (qs.S + qs.R) + qs.S)) / 2048
+    assert 1.45 < m["index", 1] / ideal < 1.55           # index order: ~1.5 x the balanced makespan
+    assert 1.33 < m["cost", 1] / ideal < 1.42            # largest initial cost first: ~1.38 x
+    assert m["exact", 1] / ideal < 1.04                  # exact foreknowledge: ~1.02 x
+    assert m["cost", 1] < m["index", 1]
+    # packing G instances per wavefront: a few per cent at G = 2 under the history-free order, a loss at G = 4, and no gain at
+    # all once the order is right -- the stragglers' latency, not lane utilisation, bounds this queue
+    assert 0.90 < m["cost", 2] / m["cost", 1] < 1.0 and m["cost", 4] >= m["cost", 1] * 0.99
+    assert m["index", 4] > m["index", 1] and m["exact", 4] > 1.5 * m["exact", 1]
