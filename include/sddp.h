@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDDP_ABI_VERSION 6
+#define SDDP_ABI_VERSION 7
 
 /* model ids */
 #define SDDP_MODEL_SRBD13 0 /* nx=13 nu=6  np=19 : BASELINE.json metric model (contacts are per-knot parameters) */
@@ -93,6 +93,15 @@ typedef struct sddp_model_consts {
     double friction_cone_coefficient;  /* 0.8, rosparam default prb.py:174 */
     double friction_barrier_weight;    /* 0 = off */
     double friction_barrier_sharpness; /* 1 */
+    /* Variable bounds: the reference's second commented-out block (ddp.py:203-208) adds, for every state and input variable and
+     * stage node, exp(exp_parameter (v - upper)) + exp(exp_parameter (lower - v)) with exp_parameter = 6 (ddp.py:182); prb.py sets
+     * no bounds.  bound_barrier_weight = 0 (default) = the reference's behaviour.  > 0 adds weight * that sum over the entries of
+     * z = [x u] whose bound is finite (lower[j] / upper[j], j < nx + nu; -inf / +inf = unbounded), Gauss-Newton Hessians like every
+     * other cost.  SRBD models only. */
+    double bound_barrier_weight;       /* 0 = off */
+    double bound_barrier_sharpness;    /* 6 */
+    double lower[64];
+    double upper[64];
 } sddp_model_consts;
 
 /* per-instance solve record (what pyddp exposes only as is_converged(), ddp.py:106, plus the tic/toc of

@@ -20,10 +20,12 @@ typedef struct {
     double mu_lin, bar_w, bar_s;   /* friction-cone exponential barrier (oracle/models.py _force_rows): off when bar_w == 0 */
     double w_rel, w_zmp, lip_h, feet[12];
     int inertia_mode;
+    double box_w, box_s, lower[64], upper[64];   /* bound barrier (oracle/models.py _bound_rows, ddp.py:203-208): off when box_w == 0 */
 } consts_t;
 
 /* packed constants from Python: m, I[9], com_z, dt, force_scaling, r_gain, rdot_gain, w_gain, fsw, qddot, minf, inertia_mode, lever,
- * friction_cone_coefficient, friction_barrier_weight, friction_barrier_sharpness, rel_pos_gain, zmp_gain, lip_height, feet[12] */
+ * friction_cone_coefficient, friction_barrier_weight, friction_barrier_sharpness, rel_pos_gain, zmp_gain, lip_height, feet[12],
+ * bound_barrier_weight, bound_barrier_sharpness, lower[64], upper[64] */
 static void unpack_consts(const double* c, consts_t* k) {
     const double m = c[0], fs = c[12];
     k->inv_ms = fs / m;
@@ -35,6 +37,8 @@ static void unpack_consts(const double* c, consts_t* k) {
     k->mu_lin = c[21] / sqrt(2.0); k->bar_w = c[22]; k->bar_s = c[23];
     k->w_rel = c[24]; k->w_zmp = c[25]; k->lip_h = c[26];
     for (int i = 0; i < 12; ++i) k->feet[i] = c[27 + i];
+    k->box_w = c[39]; k->box_s = c[40];
+    for (int i = 0; i < 64; ++i) { k->lower[i] = c[41 + i]; k->upper[i] = c[105 + i]; }
 }
 
 static void cross(const double* a, const double* b, double* o) {
@@ -305,6 +309,31 @@ static int force_rows(const consts_t* c, const double* f, double sw, int ucol, d
     }
     return n;
 }
+/* opt-in exponential barrier on the bounds of z = [x u] (ddp.py:203-208, commented out upstream): one row per finite bound,
+ * r = sqrt(w) exp(s (z_j - ub_j) / 2) resp. sqrt(w) exp(s (lb_j - z_j) / 2), upper before lower (oracle/models.py _bound_rows) */
+static int bound_rows(const consts_t* c, const double* x, const double* u, int nx, int nu, double* r, double* J, int n) {
+    if (!(c->box_w > 0.0)) return n;
+    const int nz = nx + nu;
+    const double sw = sqrt(c->box_w), hs = 0.5 * c->box_s;
+    for (int j = 0; j < nz; ++j) {
+        const double z = j < nx ? x[j] : u[j - nx];
+        if (isfinite(c->upper[j])) { r[n] = sw * exp(hs * (z - c->upper[j])); if (J) J[n * nz + j] = hs * r[n]; ++n; }
+        if (isfinite(c->lower[j])) { r[n] = sw * exp(hs * (c->lower[j] - z)); if (J) J[n * nz + j] = -hs * r[n]; ++n; }
+    }
+    return n;
+}
+/* exact minus Gauss-Newton Hessian of the bound barrier = its (diagonal) Gauss-Newton Hessian once more */
+static void bound_second_order(const consts_t* c, const double* x, const double* u, int nx, int nu, double theta, double* Q) {
+    if (!(c->box_w > 0.0)) return;
+    const int nz = nx + nu;
+    for (int j = 0; j < nz; ++j) {
+        const double z = j < nx ? x[j] : u[j - nx];
+        double e = 0.0;
+        if (isfinite(c->upper[j])) e += exp(c->box_s * (z - c->upper[j]));
+        if (isfinite(c->lower[j])) e += exp(c->box_s * (c->lower[j] - z));
+        Q[j * nz + j] += theta * 0.5 * c->box_w * c->box_s * c->box_s * e;
+    }
+}
 /* rel_pos_{y,x}_1_4 and _3_6 (prb.py:192-199), d1 = p2 - p0, d2 = p3 - p1 (prb.py:153-154): 4 rows */
 static int rel_pos_rows(const consts_t* c, const double* x, const int* C0, double* r, double* J, int nz, int n) {
     const double g = sqrt(c->w_rel);
@@ -343,7 +372,7 @@ static int contact_penalty_rows(const double* x, const int* C0, const int* CD0, 
 #define NX 13
 #define NU 6
 #define NP 19
-#define NR 39 /* residual rows of a stage node: 11 state + 18 input (+ 10 friction-cone barrier rows when enabled) */
+#define NR 77 /* residual rows of a stage node: 11 state + 18 input (+ 10 friction-cone barrier rows, + 2 x 19 bound rows when enabled) */
 #define MDL(n) s13_##n
 static void s13_core(const consts_t* c, const double* x, const double* u, const double* p, core_t* k, corejac_t* J) {
     const double* cs[2] = {p + 11, p + 14}; const double* fs[2] = {u, u + 3};
@@ -400,6 +429,7 @@ static int s13_residual_k(const consts_t* c, const double* x, const double* u, c
         }
         n += 6;
         for (int i = 0; i < 2; ++i) n = force_rows(c, u + 3 * i, p[17 + i], 13 + 3 * i, r, J, nz, n);
+        n = bound_rows(c, x, u, 13, 6, r, J, n);
     }
     return n;
 }
@@ -421,6 +451,7 @@ static void s13_second_order(const consts_t* c, const double* x, const double* u
         const double* cs[2] = {p + 11, p + 14}; const double* fs[2] = {u, u + 3};
         const int gl[22] = {0, 1, 2, 3, 4, 5, 6, 10, 11, 12, -1, -1, -1, -1, -1, -1, 13, 14, 15, 16, 17, 18};
         srbd_second_order_full(c, x, x + 3, x + 10, 2, cs, fs, vp + 3, vp + 10, gl, 3, 10, theta, Q, 19);
+        bound_second_order(c, x, u, 13, 6, theta, Q);
         return;
     }
     double R[9], M[9], Mi[9], lam[3], y[3], S[9];
@@ -445,7 +476,7 @@ static void s13_second_order(const consts_t* c, const double* x, const double* u
 #define NX 37
 #define NU 24
 #define NP 19
-#define NR 96 /* 15 state + 18 min_qddot + 24 force (+ 20 barrier) + 16 penalty rows */
+#define NR 218 /* 15 state + 18 min_qddot + 24 force (+ 20 barrier) + 16 penalty rows (+ 2 x 61 bound rows) */
 #define MDL(n) s37_##n
 static const int S37_C[4] = {7, 10, 13, 16}, S37_CD[4] = {25, 28, 31, 34};
 static void s37_core(const consts_t* c, const double* x, const double* u, core_t* k, corejac_t* J) {
@@ -523,6 +554,7 @@ static int s37_residual_k(const consts_t* c, const double* x, const double* u, c
         for (int i = 0; i < 4; ++i) { cref[i] = p[7 + 2 * i]; sw[i] = p[8 + 2 * i]; }
         for (int i = 0; i < 4; ++i) n = force_rows(c, u + 6 * i + 3, sw[i], 37 + 6 * i + 3, r, J, nz, n);
         n = contact_penalty_rows(x, S37_C, S37_CD, cref, sw, r, J, nz, n);
+        n = bound_rows(c, x, u, 37, 24, r, J, n);
     }
     return n;
 }
@@ -547,6 +579,7 @@ static void s37_second_order(const consts_t* c, const double* x, const double* u
         for (int i = 0; i < 12; ++i) gl[10 + i] = 7 + i;
         for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) gl[22 + 3 * i + a] = 37 + 6 * i + 3 + a;
         srbd_second_order_full(c, x, x + 3, x + 22, 4, cs, fs, vp + 3, vp + 22, gl, 3, 22, theta, Q, 61);
+        bound_second_order(c, x, u, 37, 24, theta, Q);
         return;
     }
     double R[9], M[9], Mi[9], lam[3], y[3], S[9];

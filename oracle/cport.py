@@ -43,8 +43,17 @@ def pack_consts(cst):
                      cst.r_tracking_gain, cst.rdot_tracking_gain, cst.w_tracking_gain, cst.force_switch_weight,
                      cst.min_qddot_gain, cst.min_f_gain, float(cst.inertia_mode), cst.lever_sign,
                      cst.friction_cone_coefficient, cst.friction_barrier_weight, cst.friction_barrier_sharpness,
-                     cst.rel_pos_gain, cst.zmp_tracking_gain, cst.lip_height, *np.asarray(cst.feet, dtype=float).reshape(-1)],
+                     cst.rel_pos_gain, cst.zmp_tracking_gain, cst.lip_height, *np.asarray(cst.feet, dtype=float).reshape(-1),
+                     cst.bound_barrier_weight, cst.bound_barrier_sharpness, *_bounds64(cst.lower, -np.inf), *_bounds64(cst.upper, np.inf)],
                     dtype=np.float64)
+
+
+def _bounds64(b, fill):
+    out = np.full(64, fill)
+    if b is not None:
+        b = np.asarray(b, dtype=float).reshape(-1)
+        out[:b.size] = b
+    return out
 
 
 def pack_opts(o):

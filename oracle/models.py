@@ -56,6 +56,13 @@ class RobotConsts:
     friction_cone_coefficient: float = 0.8      # rosparam default, prb.py:174 ; linearised as mu / sqrt(2) (Horizon, unverified)
     friction_barrier_weight: float = 0.0        # ddp.py:182 exp_parameter would be 6.0
     friction_barrier_sharpness: float = 1.0
+    # Variable bounds the reference turns into exponential barriers and then comments out (ddp.py:203-208): for every state and
+    # input variable, at the stage nodes, exp(6 (v - upper)) + exp(6 (lower - v)).  OFF by default (weight 0; and prb.py sets no
+    # bounds at all).  lower / upper: one value per entry of z = [x u] (None or +-inf: unbounded)
+    bound_barrier_weight: float = 0.0
+    bound_barrier_sharpness: float = 6.0        # exp_parameter, ddp.py:182
+    lower: np.ndarray | None = None
+    upper: np.ndarray | None = None
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -384,6 +391,7 @@ class SRBD13(Model):
             rows.add(g * np.concatenate([rddot, wdot]), g * Jx, g * Ju)          # min_qddot  prb.py:200
             for i in range(2):
                 _force_rows(rows, c, fs[i], p[self.P_SW[i]], 3 * i)
+            _bound_rows(rows, c, x, u)
         return rows.stack()
 
     def second_order_ux(self, x, u, p, vp):
@@ -396,8 +404,9 @@ class SRBD13(Model):
 
     def second_order_full(self, x, u, p, k, vp):
         r, o, rd, w, cs, fs = self._split(x, u, p)
-        return _srbd_second_order_full(self.cst, 19, r, o, w, cs, fs, vp[self.O_], vp[self.W_], self.O_.start, self.W_.start,
-                                       None, [13, 16])
+        S = _srbd_second_order_full(self.cst, 19, r, o, w, cs, fs, vp[self.O_], vp[self.W_], self.O_.start, self.W_.start,
+                                    None, [13, 16])
+        return S + np.diag(_bound_hess_extra(self.cst, x, u))
 
     def initial_state(self):
         return np.concatenate([self.cst.com, [0, 0, 0, 1.0], np.zeros(6)])        # prb.py:224-240 reduced
@@ -497,6 +506,43 @@ def _force_rows(rows, c, f, sw, ucol):
         Jf = (0.5 * c.friction_barrier_sharpness) * r[:, None] * A                 # d r_j / d f
         Ju = np.zeros((5, rows.nu)); Ju[:, ucol:ucol + 3] = Jf
         rows.add(r, None, Ju)
+
+
+def _bound_rows(rows, c, x, u):
+    """Opt-in exponential barrier on the bounds of the state and input variables (ddp.py:203-208, commented out upstream):
+    cost w [exp(s (z_j - ub_j)) + exp(s (lb_j - z_j))] per bounded entry of z = [x u], written like the friction barrier as
+    residuals r = sqrt(w) exp(s (z_j - ub_j) / 2) so that its Gauss-Newton Hessian (w s^2 / 2) e is of the common form.
+    One row per finite bound, in the order j = 0..nz-1, upper before lower."""
+    if not (c.bound_barrier_weight > 0.0):
+        return
+    nx, nu = rows.nx, rows.nu
+    z = np.concatenate([x, u])
+    lb = np.full(nx + nu, -np.inf) if c.lower is None else np.asarray(c.lower, dtype=float)[:nx + nu]
+    ub = np.full(nx + nu, np.inf) if c.upper is None else np.asarray(c.upper, dtype=float)[:nx + nu]
+    sw, hs = np.sqrt(c.bound_barrier_weight), 0.5 * c.bound_barrier_sharpness
+    for j in range(nx + nu):
+        for bound, sign in ((ub[j], 1.0), (lb[j], -1.0)):
+            if not np.isfinite(bound):
+                continue
+            r = sw * np.exp(hs * sign * (z[j] - bound))
+            Jx, Ju = np.zeros((1, nx)), np.zeros((1, nu))
+            (Jx if j < nx else Ju)[0, j if j < nx else j - nx] = hs * sign * r
+            rows.add(r, Jx, Ju)
+
+
+def _bound_hess_extra(c, x, u):
+    """exact minus Gauss-Newton Hessian of the bound barrier = its (diagonal) Gauss-Newton Hessian once more -> [nz]"""
+    nz = x.shape[0] + u.shape[0]
+    d = np.zeros(nz)
+    if not (c.bound_barrier_weight > 0.0):
+        return d
+    z = np.concatenate([x, u])
+    lb = np.full(nz, -np.inf) if c.lower is None else np.asarray(c.lower, dtype=float)[:nz]
+    ub = np.full(nz, np.inf) if c.upper is None else np.asarray(c.upper, dtype=float)[:nz]
+    with np.errstate(over="ignore"):
+        e = np.where(np.isfinite(ub), np.exp(c.bound_barrier_sharpness * (z - ub)), 0.0) + \
+            np.where(np.isfinite(lb), np.exp(c.bound_barrier_sharpness * (lb - z)), 0.0)
+    return 0.5 * c.bound_barrier_weight * c.bound_barrier_sharpness ** 2 * e
 
 
 def _contact_penalty_rows(rows, cs, cds, c_ref, sw, c_idx, cd_idx, contact_model):
@@ -619,6 +665,7 @@ class SRBD37(Model):
                 _force_rows(rows, c, fs[i], p[self.p_sw(i)], 6 * i + 3)
             _contact_penalty_rows(rows, cs, cds, [p[self.p_cref(i)] for i in range(4)],
                                   [p[self.p_sw(i)] for i in range(4)], self.C_IDX, self.CD_IDX, self.contact_model)
+            _bound_rows(rows, c, xs, u)
         return rows.stack()
 
     def second_order_ux(self, x, u, p, vp):
@@ -632,8 +679,9 @@ class SRBD37(Model):
 
     def second_order_full(self, x, u, p, k, vp):
         r, o, rd, w, cs, cds, cdd, fs = self._split(x, u)
-        return _srbd_second_order_full(self.cst, 61, r, o, w, cs, fs, vp[self.O_], vp[self.W_], self.O_.start, self.W_.start,
-                                       self.C_IDX, [37 + 6 * i + 3 for i in range(4)])
+        S = _srbd_second_order_full(self.cst, 61, r, o, w, cs, fs, vp[self.O_], vp[self.W_], self.O_.start, self.W_.start,
+                                    self.C_IDX, [37 + 6 * i + 3 for i in range(4)])
+        return S + np.diag(_bound_hess_extra(self.cst, x, u))
 
     def initial_state(self):
         feet = np.asarray(self.cst.feet)

@@ -36,7 +36,9 @@ class SddpModelConsts(C.Structure):
                 ("rel_pos_gain", C.c_double), ("force_switch_weight", C.c_double), ("min_qddot_gain", C.c_double),
                 ("min_f_gain", C.c_double), ("zmp_tracking_gain", C.c_double), ("lip_height", C.c_double),
                 ("inertia_mode", C.c_int), ("lever_sign", C.c_double), ("friction_cone_coefficient", C.c_double),
-                ("friction_barrier_weight", C.c_double), ("friction_barrier_sharpness", C.c_double)]
+                ("friction_barrier_weight", C.c_double), ("friction_barrier_sharpness", C.c_double),
+                ("bound_barrier_weight", C.c_double), ("bound_barrier_sharpness", C.c_double),
+                ("lower", C.c_double * 64), ("upper", C.c_double * 64)]
 
 
 class SddpStats(C.Structure):
@@ -132,7 +134,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.sddp_abi_version() != 6:
+    if lib.sddp_abi_version() != 7:
         raise RuntimeError("libsddp_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -157,7 +159,15 @@ def default_consts(**over) -> SddpModelConsts:
 
 def set_consts(c: SddpModelConsts, **over):
     for k, v in over.items():
-        if k in ("I", "com", "feet"):
+        if k in ("lower", "upper"):                    # bounds of z = [x u]: the first nx + nu entries, the rest stays unbounded
+            field = getattr(c, k)
+            if v is not None:
+                arr = np.asarray(v, dtype=float).reshape(-1)
+                if arr.size > len(field):
+                    raise ValueError(f"{k}: at most {len(field)} values")
+                for i, a in enumerate(arr):
+                    field[i] = float(a)
+        elif k in ("I", "com", "feet"):
             arr = np.asarray(v, dtype=float).reshape(-1)
             field = getattr(c, k)
             if arr.size != len(field):

@@ -362,6 +362,9 @@ void sddp_default_consts(sddp_model_consts* c) {
     c->friction_cone_coefficient = 0.8;      // prb.py:174
     c->friction_barrier_weight = 0.0;        // off: the reference ignores its inequality constraints (ddp.py:197-209)
     c->friction_barrier_sharpness = 1.0;
+    c->bound_barrier_weight = 0.0;           // off: the reference's bound barriers are commented out (ddp.py:203-208)
+    c->bound_barrier_sharpness = 6.0;        // exp_parameter, ddp.py:182
+    for (int i = 0; i < 64; ++i) { c->lower[i] = -HUGE_VAL; c->upper[i] = HUGE_VAL; }
 }
 
 const char* sddp_last_error(const sddp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -370,12 +373,22 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (!out) return fail(nullptr, SDDP_ERR_ARG, "out is NULL");
     *out = nullptr;
     Dims d;
-    const bool bar = consts && consts->friction_barrier_weight > 0.0 && model_id != SDDP_MODEL_LIP30;
+    if (consts && consts->bound_barrier_weight > 0.0 && model_id == SDDP_MODEL_LIP30)
+        return fail(nullptr, SDDP_ERR_ARG, "bound_barrier_weight > 0: the bound barrier exists for the SRBD models only");
+    // barrier builds: the friction-cone barrier and / or the bound barrier
+    const bool bar = consts && (consts->friction_barrier_weight > 0.0 || consts->bound_barrier_weight > 0.0) && model_id != SDDP_MODEL_LIP30;
     const bool so2 = opts && opts->second_order == 2 && model_id != SDDP_MODEL_LIP30;     // (the LIP model is linear-quadratic: nothing to add)
     if (!model_dims(model_id, d, bar, so2)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
     if (N < 1 || batch < 1) return fail(nullptr, SDDP_ERR_ARG, "N and batch must be >= 1");
-    if (consts && (consts->friction_barrier_weight < 0.0 || (bar && !(consts->friction_cone_coefficient > 0.0))))
+    if (consts && (consts->friction_barrier_weight < 0.0 || (consts->friction_barrier_weight > 0.0 && !(consts->friction_cone_coefficient > 0.0))))
         return fail(nullptr, SDDP_ERR_ARG, "friction_barrier_weight must be >= 0 and friction_cone_coefficient > 0");
+    if (consts && (consts->bound_barrier_weight < 0.0 || !std::isfinite(consts->bound_barrier_weight) ||
+                   (consts->bound_barrier_weight > 0.0 && !(consts->bound_barrier_sharpness > 0.0 && std::isfinite(consts->bound_barrier_sharpness)))))
+        return fail(nullptr, SDDP_ERR_ARG, "bound_barrier_weight must be >= 0 and bound_barrier_sharpness > 0");
+    if (consts && consts->bound_barrier_weight > 0.0)
+        for (int j = 0; j < d.nx + d.nu; ++j)
+            if (std::isnan(consts->lower[j]) || std::isnan(consts->upper[j]) || !(consts->lower[j] < consts->upper[j]))
+                return fail(nullptr, SDDP_ERR_ARG, "bound barrier: lower[j] < upper[j] is required for every j < nx + nu");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, SDDP_ERR_HIP, "no HIP device visible: the SDDP engine has no CPU fallback");
@@ -784,7 +797,7 @@ int sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk
     Dims d;
     sddp_model_consts cc;
     if (consts) cc = *consts; else sddp_default_consts(&cc);
-    const bool bar = cc.friction_barrier_weight > 0.0 && model_id != SDDP_MODEL_LIP30;
+    const bool bar = (cc.friction_barrier_weight > 0.0 || cc.bound_barrier_weight > 0.0) && model_id != SDDP_MODEL_LIP30;
     if (!model_dims(model_id, d, bar)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
     if (nk < 1 || !k || !x || !u || !p) return fail(nullptr, SDDP_ERR_ARG, "bad argument");
     const DevConsts dc = make_dev_consts(cc);

@@ -512,7 +512,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             wave_sync();
         }
         if (M::BAR) {         // friction-cone barrier builds: its Hessian blocks on the force-force diagonal of Q
-            M::add_barrier(s + L::REC, s + L::Q, SQ, lane, kWave);
+            M::add_barrier(s + L::REC, s + L::Q, SQ, lane, kWave, M::SO2 ? theta : 0.0);
             wave_sync();
         }
         SDDP_TICK(4)

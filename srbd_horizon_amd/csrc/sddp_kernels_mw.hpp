@@ -330,7 +330,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             __syncthreads();
         }
         if (M::BAR) {         // friction-cone barrier builds: its Hessian blocks on the force-force diagonal of Q
-            M::add_barrier(s + L::REC, s + L::Q, SQ, tid, kThreadsMW);
+            M::add_barrier(s + L::REC, s + L::Q, SQ, tid, kThreadsMW, M::SO2 ? theta : 0.0);
             __syncthreads();
         }
         SDDP_TICK(4)

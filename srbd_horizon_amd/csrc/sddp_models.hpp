@@ -30,6 +30,8 @@ struct DevConsts {
     double lever;
     double mu_lin, bar_w, bar_s;   // friction-cone exponential barrier (BAR models only): linearised coefficient, weight, sharpness
     int inertia_mode;
+    double box_w, box_s;           // bound barrier (BAR models only, sddp.h): weight (0: off), sharpness
+    double lower[64], upper[64];   // ... bounds of z = [x u]; read with compile-time indices (scalar loads from the kernarg segment)
 };
 
 inline DevConsts make_dev_consts(const sddp_model_consts& c) {
@@ -58,6 +60,9 @@ inline DevConsts make_dev_consts(const sddp_model_consts& c) {
     d.mu_lin = c.friction_cone_coefficient / sqrt(2.0);
     d.bar_w = c.friction_barrier_weight;
     d.bar_s = c.friction_barrier_sharpness;
+    d.box_w = c.bound_barrier_weight;
+    d.box_s = c.bound_barrier_sharpness;
+    for (int i = 0; i < 64; ++i) { d.lower[i] = c.lower[i]; d.upper[i] = c.upper[i]; }
     return d;
 }
 
@@ -238,7 +243,8 @@ struct SrbdModel {
     // derivative record of one knot
     static constexpr int REC_A = 0, REC_JO = 3 * NA, REC_JW = REC_JO + 16, REC_MI = REC_JW + 12, REC_G = REC_MI + 9,
                          REC_B = REC_G + NZ,                       // BAR: barrier Hessian per contact: hxx hyy hzz hxz hyz
-                         REC_WD = REC_B + (BAR ? 5 * NC : 0),      // SO2 (full second-order builds): compact factors of the wdot
+                         REC_BB = REC_B + (BAR ? 5 * NC : 0),      // BAR: Gauss-Newton Hessian (diagonal) of the bound barrier, NZ words
+                         REC_WD = REC_BB + (BAR ? NZ : 0),         // SO2 (full second-order builds): compact factors of the wdot
                          REC_M = REC_WD + 3,                       //   Hessian, contracted in the sweep (add_second_order):
                          REC_DM = REC_M + 9,                       //   wdot (3) | I_w (9) | dI_w/do_a (4 x 9) |
                          REC_COO = REC_DM + 36,                    //   w x (d2I_w/do_a do_b w) + d2I_w/do_a do_b wdot for the 10
@@ -358,6 +364,33 @@ struct SrbdModel {
         return hi == 2 ? h[3 + lo] : 0.0;
     }
 
+    // opt-in barrier on the bounds of z = [x u] (BAR builds, sddp.h; ddp.py:203-208): w sum_j [exp(s (z_j - ub_j)) + exp(s (lb_j - z_j))]
+    // over the finite bounds.  Compile-time j: the bounds are scalar loads and the test for a finite bound a scalar branch.
+    // grad / hdiag (derivative phase): gradient added into grad[j], Gauss-Newton Hessian (w s^2 / 2) e of the residual form
+    // r = sqrt(w) exp(s (z - ub) / 2) written to hdiag[j] (0 where unbounded)
+    template <class XV, class UV>
+    __device__ __forceinline__ static double bound_cost(const DevConsts& c, XV x, UV u, double* grad = nullptr, double* hdiag = nullptr) {
+        double L = 0.0;
+        if (c.box_w > 0.0) {
+            const double ws = c.box_w * c.box_s, k2 = 0.5 * ws * c.box_s;
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) {
+                const double z = j < NX ? x[j < NX ? j : 0] : u[j < NX ? 0 : j - NX];
+                double eu = 0.0, el = 0.0;
+                if (c.upper[j] < 1e300) eu = exp(c.box_s * (z - c.upper[j]));
+                if (c.lower[j] > -1e300) el = exp(c.box_s * (c.lower[j] - z));
+                L += eu + el;
+                if (grad) grad[j] += ws * (eu - el);
+                if (hdiag) hdiag[j] = k2 * (eu + el);
+            }
+            L *= c.box_w;
+        } else if (hdiag) {
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) hdiag[j] = 0.0;
+        }
+        return L;
+    }
+
     // cost of the input residuals + penalties given rddot/wdot (nodes 0..ns-1, prb.py:200-204, :166-181)
     template <class XV, class UV>
     __device__ __forceinline__ static double input_cost(const DevConsts& c, XV x, UV u, const double* p,
@@ -401,6 +434,7 @@ struct SrbdModel {
         const double w[3] = {x[XW], x[XW + 1], x[XW + 2]};
         core(c, r, o, w, cp, f, q);
         double L = input_cost(c, x, u, p, f, q);
+        if (BAR) L += bound_cost(c, x, u);
         if (k >= 1) L += state_cost(c, x, p);
         // every component of x+ is formed from values read BEFORE the first store: x and xn may be the same array (in-place
         // rollout) or LDS columns the compiler cannot tell apart (then interleaved loads and stores would serialise)
@@ -599,6 +633,12 @@ struct SrbdModel {
                     g[XCD + 3 * b + 1] += sp * ey; g[XCD + 3 * b + 4] -= sp * ey;
                 }
             }
+            if (BAR) {      // bound barrier (off: zeros): gradient into g, Gauss-Newton Hessian diagonal into the record
+                double hb[NZ];
+                (void)bound_cost(c, x, u, g, hb);
+#pragma unroll
+                for (int i = 0; i < NZ; ++i) rec[REC_BB + i] = hb[i];
+            }
 #pragma unroll
             for (int i = 0; i < NZ; ++i) rec[REC_G + i] = g[i];
             if (SO2) so2_record(c, o, w, q, rec);       // last: A and the gradient are stored, only the core quantities are live
@@ -767,6 +807,7 @@ struct SrbdModel {
             }
         }
         if (BAR && stage && cli == V_F && clj == V_F && ci == cj) v += barrier_h(rec + REC_B + 5 * ci, ai, aj);
+        if (BAR && stage && i == j) v += rec[REC_BB + i];
         if (stage) {
             const int a = acol(i), b = acol(j);
             if (a >= 0 && b >= 0)
@@ -1075,10 +1116,20 @@ struct SrbdModel {
     }
 
     // BAR builds: the barrier's Gauss-Newton Hessian blocks (3x3 per contact force, from the record) added to Quu
-    __device__ __forceinline__ static void add_barrier(const double* rec, double* Q, int ld, int lane, int nlanes) {
-        for (int e = lane; e < 9 * NC; e += nlanes) {
-            const int i = e / 9, a = (e % 9) / 3, b = e % 3;
-            Q[(NX + uf(i) + a) * ld + NX + uf(i) + b] += barrier_h(rec + REC_B + 5 * i, a, b);
+    // ... and the diagonal of the bound barrier; so2_theta (SO2 builds: theta of this sweep, else 0): its exact Hessian is twice the
+    // Gauss-Newton one, like the friction barrier's (whose share is added in add_second_order)
+    __device__ __forceinline__ static void add_barrier(const double* rec, double* Q, int ld, int lane, int nlanes, double so2_theta = 0.0) {
+        for (int e = lane; e < 9 * NC + NZ; e += nlanes) {      // every entry of Q is updated by exactly one lane
+            if (e < 9 * NC) {
+                const int i = e / 9, a = (e % 9) / 3, b = e % 3, j = NX + uf(i) + a;
+                double v = barrier_h(rec + REC_B + 5 * i, a, b);
+                if (a == b) v += (1.0 + so2_theta) * rec[REC_BB + j];          // the force diagonals take their bound term here
+                Q[j * ld + NX + uf(i) + b] += v;
+            } else {
+                const int j = e - 9 * NC;
+                const bool force = j >= NX && (!CS || (j - NX) % 6 >= 3);
+                if (!force) Q[j * ld + j] += (1.0 + so2_theta) * rec[REC_BB + j];
+            }
         }
     }
 };
@@ -1090,10 +1141,11 @@ struct SrbdModel {
 struct LipModel {
     static constexpr int NC = 4;
     static constexpr bool BAR = false;
-    __device__ __forceinline__ static void add_barrier(const double*, double*, int, int, int) {}
+    __device__ __forceinline__ static void add_barrier(const double*, double*, int, int, int, double = 0.0) {}
     static constexpr int NX = 30, NU = 15, NZ = 45, NP = 11;
     static constexpr int XR = 0, XC = 3, XRD = 15, XCD = 18;
     static constexpr int REC_G = 0, NREC = NZ, NSO2T = 0, NSO2L = 0;
+    static constexpr bool SO2 = false;
     __device__ __forceinline__ static void so2_prepare(const DevConsts&, const double*, const double*, double*, int, int) {}
     __device__ __forceinline__ static void so2_pair_code(int, int&, int&) {}
     __device__ __forceinline__ static double p_cref(const double* p, int i) { return p[3 + 2 * i]; }

@@ -26,6 +26,9 @@ from .problem import Problem
 _REFERENCE_KEYS = ("max_iters", "alpha_0", "alpha_converge_threshold", "line_search_decrease_factor", "beta",
                    "cost_reduction_ths", "mu0")
 _EXTRA_KEYS = ("initial_rollout", "gap_tol", "mu_min", "mu_max", "second_order", "waves_per_simd", "queue_order", "max_slots")
+# the reference's commented-out bound barrier (ddp.py:203-208) as an opt-in: weight 0 / absent = the reference's behaviour (variable
+# bounds ignored); > 0: exponential barrier on the bounds set with Variable.setBounds, sharpness = exp_parameter (ddp.py:182)
+_BARRIER_KEYS = ("bound_barrier_weight", "bound_barrier_sharpness")
 
 # What each registered analytic model implements, by the reference's function names (prb.py:166-204, :379-402):
 #   cost:  name -> (model constant that carries its gain or None, "state" = nodes 1..ns | "stage" = nodes 0..ns-1)
@@ -65,9 +68,10 @@ class DDPSolver:
             raise ValueError("the problem has no registered analytic model (Problem.setModel)")
         self.prb = prb
         self.opts = dict(opts or {})
-        unknown = [k for k in self.opts if k not in _REFERENCE_KEYS + _EXTRA_KEYS]
+        unknown = [k for k in self.opts if k not in _REFERENCE_KEYS + _EXTRA_KEYS + _BARRIER_KEYS]
         if unknown:
             raise KeyError(f"unknown DDP option(s): {unknown}")
+        barrier = {k: float(self.opts.pop(k)) for k in _BARRIER_KEYS if k in self.opts}
         self.state_var = prb.getState().getVars()
         self.state_size = sum(v.getDim() for v in self.state_var)
         self.input_var = prb.getInput().getVars()
@@ -77,6 +81,11 @@ class DDPSolver:
         consts = self._model_consts_from_functions()
         if prb.getDt() is not None:
             consts["dt"] = prb.getDt()
+        if barrier.get("bound_barrier_weight", 0.0) > 0.0:
+            # variable bounds -> entries of z = [x u] in creation order (ddp.py:203-208 walks var_container.getVarList)
+            consts.update(barrier)
+            consts["lower"] = np.concatenate([v.getLowerBounds() for v in list(self.state_var) + list(self.input_var)])
+            consts["upper"] = np.concatenate([v.getUpperBounds() for v in list(self.state_var) + list(self.input_var)])
         self.ddp_solver = DdpEngine(prb.model, prb.nodes - 1, 1, opts=self.opts, consts=consts)
         if (self.ddp_solver.nx, self.ddp_solver.nu) != (self.state_size, self.input_size):
             raise ValueError("problem variables do not match the registered model's dimensions")

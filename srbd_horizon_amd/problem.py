@@ -21,6 +21,35 @@ import numpy as np
 class Variable:
     def __init__(self, name: str, dim: int, kind: str):
         self._name, self._dim, self.kind = name, int(dim), kind
+        self._lb, self._ub = np.full(self._dim, -np.inf), np.full(self._dim, np.inf)     # Horizon's default: unbounded
+
+    # Horizon's variable bounds (same for every node here).  The reference's DDP adapter would turn them into exponential barriers
+    # (ddp.py:203-208) but that block is commented out, and prb.py sets none: they only act with the solver option
+    # "bound_barrier_weight" > 0 (srbd_horizon_amd/ddp.py)
+    def setBounds(self, lb, ub, nodes=None):
+        if nodes is not None:
+            raise NotImplementedError("node-dependent variable bounds are not implemented")
+        self.setLowerBounds(lb)
+        self.setUpperBounds(ub)
+
+    def setLowerBounds(self, lb, nodes=None):
+        if nodes is not None:
+            raise NotImplementedError("node-dependent variable bounds are not implemented")
+        self._lb = np.broadcast_to(np.asarray(lb, dtype=float).reshape(-1), (self._dim,)).copy()
+
+    def setUpperBounds(self, ub, nodes=None):
+        if nodes is not None:
+            raise NotImplementedError("node-dependent variable bounds are not implemented")
+        self._ub = np.broadcast_to(np.asarray(ub, dtype=float).reshape(-1), (self._dim,)).copy()
+
+    def getLowerBounds(self):
+        return self._lb.copy()
+
+    def getUpperBounds(self):
+        return self._ub.copy()
+
+    def getBounds(self):
+        return self._lb.copy(), self._ub.copy()
 
     def getName(self):
         return self._name

@@ -26,7 +26,7 @@ def test_header_symbols_are_all_bound_and_exported(lib):
 
 
 def test_struct_layouts_and_dims(lib):
-    assert lib.sddp_abi_version() == 6
+    assert lib.sddp_abi_version() == 7
     assert _lib.model_dims("srbd13") == (13, 6, 19)
     assert _lib.model_dims("srbd37") == (37, 24, 19)
     assert _lib.model_dims("lip30") == (30, 15, 11)

@@ -1,0 +1,124 @@
+"""The reference's second commented-out inequality block (ddp.py:203-208): exponential barriers on the bounds of the state and
+input variables, here an opt-in (`bound_barrier_weight`, off by default like upstream, where prb.py sets no bounds at all).
+Barrier builds of the SRBD kernels against the oracle: per-knot value / gradient / Hessian, whole solves in the Gauss-Newton,
+default and full second-order modes, together with the friction barrier, through the problem facade, and the error paths."""
+import numpy as np
+import pytest
+
+from oracle import ddp as oddp, models as omodels
+from srbd_horizon_amd import workload
+from srbd_horizon_amd.ddp import DDPSolver
+from srbd_horizon_amd.engine import DdpEngine, eval_knots
+from srbd_horizon_amd.prb import SRBD13Problem
+
+pytestmark = pytest.mark.gpu
+
+OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsrbd_example.py:55-58
+
+
+def _bounds(name):
+    """CoM height band and a cap / floor on every vertical contact force (scaled forces: static load = 0.196 resp. 0.098)"""
+    nx, nu = (13, 6) if name == "srbd13" else (37, 24)
+    lo, up = np.full(nx + nu, -np.inf), np.full(nx + nu, np.inf)
+    lo[2], up[2] = 0.80, 0.95
+    fz = [nx + 2, nx + 5] if name == "srbd13" else [nx + 6 * i + 5 for i in range(4)]
+    for j in fz:
+        lo[j], up[j] = 0.0, (0.25 if name == "srbd13" else 0.125)
+    return dict(bound_barrier_weight=1.0, bound_barrier_sharpness=6.0, lower=lo, upper=up)      # weight 1, exp_parameter 6: ddp.py:182, :205-208
+
+
+def _model(name, consts):
+    cst = omodels.RobotConsts()
+    for k, v in consts.items():
+        if hasattr(cst, k):
+            setattr(cst, k, v)
+    return omodels.make_model(name, cst)
+
+
+@pytest.mark.parametrize("name", ["srbd13", "srbd37"])
+@pytest.mark.parametrize("friction", [0.0, 3.0])
+def test_bound_barrier_knots_match_oracle(name, friction):
+    N = 20
+    consts = dict(_bounds(name), friction_barrier_weight=friction, friction_barrier_sharpness=4.0)
+    m = _model(name, consts)
+    rng = np.random.default_rng(11)
+    ks = np.array([0, 1, 7, N - 1, N], dtype=np.int32)
+    nk = len(ks)
+    X = np.tile(m.initial_state(), (nk, 1)) + 0.05 * rng.standard_normal((nk, m.nx))
+    U = np.tile(m.static_input(), (nk, 1)) + 0.05 * rng.standard_normal((nk, m.nu))
+    P = np.tile(m.default_params(N)[3], (nk, 1)) + 0.05 * rng.standard_normal((nk, m.np_))
+    f, F, H, g, L = eval_knots(name, N, ks, X, U, P, consts=consts)
+    f0, F0, H0, g0, L0 = eval_knots(name, N, ks, X, U, P)
+    assert np.all(L[:-1] > L0[:-1]) and L[-1] == L0[-1]                  # stage nodes carry the barrier, the terminal node not
+    np.testing.assert_array_equal(f, f0)
+    np.testing.assert_array_equal(F, F0)
+    for t, k in enumerate(ks[:-1]):
+        Lo, lx, lu, lxx, lux, luu = m.cost_derivs(X[t], U[t], P[t], int(k))
+        Ho = np.block([[lxx, lux.T], [lux, luu]])
+        go = np.concatenate([lx, lu])
+        assert abs(L[t] - Lo) <= 1e-12 * max(1.0, abs(Lo))
+        np.testing.assert_allclose(g[t], go, rtol=1e-11, atol=1e-11 * max(1.0, np.max(np.abs(go))))
+        np.testing.assert_allclose(H[t], Ho, rtol=1e-11, atol=1e-11 * max(1.0, np.max(np.abs(Ho))))
+
+
+@pytest.mark.parametrize("name,N,so", [("srbd13", 30, 1), ("srbd13", 30, 0), ("srbd13", 30, 2), ("srbd37", 20, 1), ("srbd37", 20, 2)])
+def test_bound_barrier_solve_matches_oracle_and_pulls_the_forces_inside(name, N, so):
+    seeds = [0, 3]
+    batch = workload.make_batch(name, N, seeds)
+    consts = dict(batch["consts"], **_bounds(name))
+    m = _model(name, consts)
+    res = {}
+    for tag, cc in (("off", dict(batch["consts"])), ("on", consts)):
+        eng = DdpEngine(name, N, len(seeds), opts=dict(OPTS, second_order=so), consts=cc)
+        eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+        x, u = eng.solve(batch["params"])
+        res[tag] = (x, u, eng.stats.copy())
+    x, u, st = res["on"]
+    for b in range(len(seeds)):
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], oddp.DdpOptions(**dict(OPTS, second_order=so)))
+        assert st["iters"][b] == r.iters and bool(st["converged"][b]) == r.converged and st["status"][b] == r.status, (b, st[b], r.iters)
+        assert np.max(np.abs(x[b] - r.xs)) <= 1e-6 and np.max(np.abs(u[b] - r.us)) <= 1e-6
+        assert abs(st["cost"][b] - r.cost) <= 1e-9 * abs(r.cost)
+    nx = 13 if name == "srbd13" else 37
+    fz = [2, 5] if name == "srbd13" else [6 * i + 5 for i in range(4)]
+    cap = consts["upper"][nx + fz[0]]
+    over = {t: float(np.max(res[t][1][..., fz]) - cap) for t in res}
+    assert over["off"] > 0.0 and over["on"] < over["off"], over              # the unbounded solve exceeds the cap, the barrier pulls it back
+
+
+def test_bound_barrier_through_the_problem_facade_and_error_paths():
+    """Variable.setBounds + the solver option `bound_barrier_weight` (absent: bounds ignored, like the reference with its block
+    commented out) = the engine called with lower / upper; invalid settings are refused."""
+    N = 30
+    batch = workload.make_batch("srbd13", N, [5])
+    pb = SRBD13Problem()
+    pb.createSRBD13Problem(N, N * 0.05)
+    pb.prb.parameter_matrix()[...] = 0.0
+    for par, col in zip(pb.prb.getParameters().values(), np.split(batch["params"][0].T, np.cumsum([p.getDim() for p in pb.prb.getParameters().values()])[:-1])):
+        par.assign(col)
+    for v in pb.prb.getInput().getVars():
+        v.setBounds([-np.inf, -np.inf, 0.0], [np.inf, np.inf, 0.25])
+    sols = {}
+    for tag, extra in (("ignored", {}), ("barrier", dict(bound_barrier_weight=1.0, bound_barrier_sharpness=6.0))):
+        s = DDPSolver(pb.prb, dict(OPTS, **extra))
+        s.setInitialState(batch["x0"][0])
+        s.set_x_warmstart(batch["xs"][0].T); s.set_u_warmstart(batch["us"][0].T)
+        s.solve()
+        sols[tag] = (s.getSolutionDict()["u_opt"].copy(), s.stats.copy())
+    lo, up = np.full(19, -np.inf), np.full(19, np.inf)
+    lo[[15, 18]], up[[15, 18]] = 0.0, 0.25
+    e = DdpEngine("srbd13", N, 1, opts=OPTS, consts=dict(batch["consts"], bound_barrier_weight=1.0, lower=lo, upper=up))
+    e.set_initial_state(batch["x0"]); e.set_x_warmstart(batch["xs"]); e.set_u_warmstart(batch["us"])
+    x, u = e.solve(batch["params"])
+    np.testing.assert_array_equal(sols["barrier"][0], u[0].T)
+    e0 = DdpEngine("srbd13", N, 1, opts=OPTS, consts=dict(batch["consts"]))
+    e0.set_initial_state(batch["x0"]); e0.set_x_warmstart(batch["xs"]); e0.set_u_warmstart(batch["us"])
+    x0, u0 = e0.solve(batch["params"])
+    np.testing.assert_array_equal(sols["ignored"][0], u0[0].T)               # bounds without the option: the reference's behaviour
+    assert sols["barrier"][0][[2, 5]].max() < sols["ignored"][0][[2, 5]].max()
+    with pytest.raises(RuntimeError, match="bound_barrier"):
+        DdpEngine("srbd13", N, 1, consts=dict(bound_barrier_weight=-1.0))
+    with pytest.raises(RuntimeError, match="lower"):
+        DdpEngine("srbd13", N, 1, consts=dict(bound_barrier_weight=1.0, lower=np.full(19, 1.0), upper=np.full(19, 0.0)))
+    with pytest.raises(RuntimeError, match="SRBD models only"):
+        DdpEngine("lip30", 20, 1, consts=dict(bound_barrier_weight=1.0))

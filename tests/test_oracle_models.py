@@ -240,3 +240,40 @@ def test_full_second_order_term_matches_sympy_hessian():
     S = m.second_order_full(x, u, p, 3, vp)
     ref = np.asarray(H(list(x), list(u), list(p), list(vp)), dtype=float)
     np.testing.assert_allclose(S, ref, rtol=0, atol=1e-9 * max(1.0, np.max(np.abs(ref))))
+
+
+@pytest.mark.parametrize("name", ["srbd13", "srbd37"])
+def test_bound_barrier_rows_match_finite_differences_and_the_c_oracle(name):
+    """Opt-in exponential barrier on variable bounds (ddp.py:203-208, commented out upstream): cost = w sum exp(s (z - ub)) +
+    exp(s (lb - z)); gradient by central differences; Gauss-Newton Hessian = w s^2 / 2 e on the diagonal; the C oracle agrees;
+    off (default) = no rows."""
+    from oracle import cport, models as omodels
+    nx, nu = (13, 6) if name == "srbd13" else (37, 24)
+    nz = nx + nu
+    lo, up = np.full(nz, -np.inf), np.full(nz, np.inf)
+    lo[2], up[2], up[nx + 2], lo[nz - 1] = 0.8, 0.9, 0.2, 0.0
+    cst = omodels.RobotConsts(bound_barrier_weight=2.0, bound_barrier_sharpness=6.0, lower=lo, upper=up)
+    m, m0 = omodels.make_model(name, cst), omodels.make_model(name)
+    rng = np.random.default_rng(2)
+    x = m.initial_state() + 0.02 * rng.standard_normal(nx)
+    u = m.static_input() + 0.02 * rng.standard_normal(nu)
+    p = m.default_params(5)[1]
+    r, Jx, Ju = m.residual_jac(x, u, p, 1)
+    r0, _, _ = m0.residual_jac(x, u, p, 1)
+    assert len(r) == len(r0) + 4                                        # one row per finite bound
+    z = np.concatenate([x, u])
+    want = 2.0 * (np.exp(6 * (z[2] - 0.9)) + np.exp(6 * (0.8 - z[2])) + np.exp(6 * (z[nx + 2] - 0.2)) + np.exp(6 * (0.0 - z[nz - 1])))
+    assert abs((r @ r - r0 @ r0) - want) <= 1e-9 * want
+    g = 2 * np.hstack([Jx, Ju]).T @ r
+    L = lambda zz: float(np.sum(m.residual_jac(zz[:nx], zz[nx:], p, 1)[0] ** 2))
+    for j in (2, nx + 2, nz - 1, 0):
+        e = np.zeros(nz); e[j] = 1e-6
+        assert abs((L(z + e) - L(z - e)) / 2e-6 - g[j]) <= 1e-6 * max(1.0, abs(g[j]))
+    rt, _, _ = m.residual_jac(x, None, p, 5)
+    r0t, _, _ = m0.residual_jac(x, None, p, 5)
+    assert len(rt) == len(r0t)                                          # no barrier at the terminal node (get_L_term has none)
+    f, F, H, gc, Lc = cport.eval_knot(cst, x, u, p, 1, False, model=name)
+    J = np.hstack([Jx, Ju])
+    assert abs(Lc - r @ r) <= 1e-12 * abs(Lc)
+    np.testing.assert_allclose(gc, g, rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(H, 2 * J.T @ J, rtol=1e-11, atol=1e-9)
