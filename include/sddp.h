@@ -189,6 +189,12 @@ int  sddp_set_params(sddp_handle* h, const double* params /*[B][N+1][np]*/);
 int  sddp_advance(sddp_handle* h, const double* p_last /*[B][np]*/, const double* x0 /*[B][nx]*/);
 /* sddp_solve on the resident parameters */
 int  sddp_solve_resident(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats /*[B] or NULL*/);
+/* sddp_solve_resident for a fleet in closed loop: what a tick applies is the first input and the state the plan expects next
+ * (dsrbd_example.py:158: u_opt[:, 0]), so only u_0 [B][nu], x_1 [B][nx], the cost and the iteration count / status of every
+ * instance leave the device (one small copy); the trajectories stay in HBM as the next tick's warm start (sddp_advance) and can
+ * still be read with sddp_fetch.  cost_out / iters_out / status_out may be NULL. */
+int  sddp_solve_resident_first(sddp_handle* h, double* u0_out /*[B][nu]*/, double* x1_out /*[B][nx]*/, double* cost_out /*[B]*/,
+                               int* iters_out /*[B]*/, int* status_out /*[B]*/);
 /* one model step per instance, x_next = f_k(x, u; p) with the handle's model and constants: the closed-loop simulator step
  * of the examples (dsrbd_example.py:158-159: integrator EULER of the same dae, :76) through the solver's own device model
  * code.  k = stage node whose parameters p are (0 <= k < N).  Host pointers; synchronous. */

@@ -64,6 +64,7 @@ SYMBOLS = {
     "sddp_set_params": (C.c_int, [_vp, _vp]),
     "sddp_advance": (C.c_int, [_vp, _vp, _vp]),
     "sddp_solve_resident": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "sddp_solve_resident_first": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sddp_model_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
     "sddp_create": (C.c_int, [_P(_vp), C.c_int, C.c_int, C.c_int, _P(SddpOptions), _P(SddpModelConsts)]),
     "sddp_destroy": (None, [_vp]),

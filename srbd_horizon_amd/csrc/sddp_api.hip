@@ -84,6 +84,8 @@ struct sddp_handle {
     struct KInfo { const void* fn = nullptr; int slots = 0; };
     KInfo kinfo[2];                 // per kernel build: dynamic-LDS attribute set, resident workgroups on this device
     int last_grid = 0, last_queued = 0;
+    double* first_dev = nullptr;    // [B][nu + nx + 2] packed first knots of sddp_solve_resident_first, and its pinned host image
+    double* first_pin = nullptr;
     char* up_pin = nullptr;         // pinned ring for small host->device uploads of the setters (no wait per call)
     size_t up_off = 0;
 
@@ -466,6 +468,8 @@ void sddp_destroy(sddp_handle* h) {
     if (h->step_pin) (void)hipHostFree(h->step_pin);
     if (h->tick_pin) (void)hipHostFree(h->tick_pin);
     if (h->up_pin) (void)hipHostFree(h->up_pin);
+    if (h->first_pin) (void)hipHostFree(h->first_pin);
+    if (h->first_dev) (void)hipFree(h->first_dev);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -705,6 +709,41 @@ int sddp_solve_resident(sddp_handle* h, double* x_out, double* u_out, sddp_stats
     rc = fetch_results(h, x_out, u_out, stats);
     h->have_xws = true;
     return rc;
+}
+
+int sddp_solve_resident_first(sddp_handle* h, double* u0_out, double* x1_out, double* cost_out, int* iters_out, int* status_out) {
+    int rc = check_ready(h);
+    if (rc != SDDP_OK) return rc;
+    if (!h->have_params) return fail(h, SDDP_ERR_ARG, "sddp_set_params has not been called");
+    if (!u0_out || !x1_out) return fail(h, SDDP_ERR_ARG, "NULL argument");
+    rc = sddp_solve_device(h, h->P);
+    if (rc != SDDP_OK) return rc;
+    const int w = h->d.nu + h->d.nx + 2;
+    const size_t bytes = size_t(h->B) * w * sizeof(double);
+    if (!h->first_dev) {
+        HIP_TRY(h, hipMalloc((void**)&h->first_dev, bytes));
+        if (hipHostMalloc((void**)&h->first_pin, bytes, hipHostMallocDefault) != hipSuccess) { h->first_pin = nullptr; (void)hipGetLastError(); }
+    }
+    const int grid = int(std::min<size_t>((size_t(h->B) * w + 255) / 256, 1024));
+    hipLaunchKernelGGL(first_knot_kernel, dim3(grid), dim3(256), 0, h->stream, h->N, h->B, h->d.nx, h->d.nu, h->xs, h->us, h->stats, h->first_dev);
+    HIP_TRY(h, hipGetLastError());
+    std::vector<double> tmp;
+    double* host = h->first_pin;
+    if (!host) { tmp.resize(size_t(h->B) * w); host = tmp.data(); }
+    HIP_TRY(h, hipMemcpyAsync(host, h->first_dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    rc = sddp_synchronize(h);
+    if (rc != SDDP_OK) return rc;
+    for (int b = 0; b < h->B; ++b) {
+        const double* r = host + size_t(b) * w;
+        std::memcpy(u0_out + size_t(b) * h->d.nu, r, h->d.nu * sizeof(double));
+        std::memcpy(x1_out + size_t(b) * h->d.nx, r + h->d.nu, h->d.nx * sizeof(double));
+        if (cost_out) cost_out[b] = r[h->d.nu + h->d.nx];
+        const int code = int(r[h->d.nu + h->d.nx + 1]);
+        if (iters_out) iters_out[b] = code & 0xffff;
+        if (status_out) status_out[b] = (code >> 16) & 0xff;
+    }
+    h->have_xws = true;
+    return SDDP_OK;
 }
 
 int sddp_model_step(sddp_handle* h, const double* x, const double* u, const double* p, int k, double* x_next) {

@@ -105,6 +105,18 @@ class DdpEngine:
         self.stats = st
         return x, u
 
+    def solve_resident_first(self):
+        """One tick of a fleet in closed loop: solve on the resident data, fetch only u_0 [B,nu], x_1 [B,nx], cost, iterations and
+        status per robot (the trajectories stay on the device as the next warm start).  -> (u0, x1); self.first_stats"""
+        u0 = np.empty((self.B, self.nu))
+        x1 = np.empty((self.B, self.nx))
+        cost = np.empty(self.B)
+        iters = np.empty(self.B, dtype=np.int32)
+        status = np.empty(self.B, dtype=np.int32)
+        self._chk(self.lib.sddp_solve_resident_first(self.h, _lib.ptr(u0), _lib.ptr(x1), _lib.ptr(cost), _lib.ptr(iters), _lib.ptr(status)))
+        self.first_stats = dict(cost=cost, iters=iters, status=status)
+        return u0, x1
+
     def is_converged(self):
         f = np.zeros(self.B, dtype=np.int32)
         self._chk(self.lib.sddp_is_converged(self.h, _lib.ptr(f)))

@@ -251,3 +251,30 @@ def test_fleet_tick_of_1024_robots_matches_the_c_oracle_tick_by_tick():
         for i in np.nonzero(both)[0]:
             assert max(np.max(np.abs(x[i] - xo[i])), np.max(np.abs(u[i] - uo[i]))) <= 1e-4, (t, i)
     assert eng.stats["iters"].mean() < 8                          # warm-started ticks, not cold solves
+
+
+def test_first_knot_fetch_equals_the_full_fetch():
+    """sddp_solve_resident_first (a fleet's closed-loop tick: only u_0, x_1, cost, iterations, status leave the device) returns
+    exactly what sddp_solve_resident returns at those positions, over a few ticks, and leaves the trajectories on the device."""
+    N, B = 30, 200
+    b = workload.make_batch("srbd13", N, np.arange(B) + 300)
+    engs = []
+    for _ in range(2):
+        e = DdpEngine("srbd13", N, B, opts=OPTS)
+        e.set_initial_state(b["x0"]); e.set_x_warmstart(b["xs"]); e.set_u_warmstart(b["us"]); e.set_params(b["params"])
+        engs.append(e)
+    full, first = engs
+    p_last = b["params"][:, -1].copy()
+    x, u = full.solve_resident()
+    u0, x1 = first.solve_resident_first()
+    for t in range(4):
+        np.testing.assert_array_equal(u0, u[:, 0])
+        np.testing.assert_array_equal(x1, x[:, 1])
+        np.testing.assert_array_equal(first.first_stats["iters"], full.stats["iters"])
+        np.testing.assert_array_equal(first.first_stats["status"], full.stats["status"])
+        np.testing.assert_array_equal(first.first_stats["cost"], full.stats["cost"])
+        xf, uf, _ = first.fetch()                                       # the whole solution is still there
+        np.testing.assert_array_equal(xf, x); np.testing.assert_array_equal(uf, u)
+        full.advance(p_last, x[:, 1].copy()); first.advance(p_last, x1.copy())
+        x, u = full.solve_resident()
+        u0, x1 = first.solve_resident_first()
