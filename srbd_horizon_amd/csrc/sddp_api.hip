@@ -84,6 +84,7 @@ struct sddp_handle {
     struct KInfo { const void* fn = nullptr; int slots = 0; };
     KInfo kinfo[2];                 // per kernel build: dynamic-LDS attribute set, resident workgroups on this device
     int last_grid = 0, last_queued = 0;
+    double* box_dev = nullptr;      // lower[64] | upper[64] of the bound barrier (barrier builds)
     double* first_dev = nullptr;    // [B][nu + nx + 2] packed first knots of sddp_solve_resident_first, and its pinned host image
     double* first_pin = nullptr;
     char* up_pin = nullptr;         // pinned ring for small host->device uploads of the setters (no wait per call)
@@ -404,6 +405,13 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     h->dc = make_dev_consts(h->consts);
     auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
     hipError_t e = hipSuccess;
+    if (bar) {   // the bounds of the bound barrier live in device memory (DevConsts::box)
+        double hb[128];
+        for (int i = 0; i < 64; ++i) { hb[i] = h->consts.lower[i]; hb[64 + i] = h->consts.upper[i]; }
+        e = alloc((void**)&h->box_dev, sizeof(hb));
+        if (e == hipSuccess) e = hipMemcpy(h->box_dev, hb, sizeof(hb), hipMemcpyHostToDevice);
+        h->dc.box = h->box_dev;
+    }
     const size_t D = sizeof(double);
     {
         int dev = 0;
@@ -470,6 +478,7 @@ void sddp_destroy(sddp_handle* h) {
     if (h->up_pin) (void)hipHostFree(h->up_pin);
     if (h->first_pin) (void)hipHostFree(h->first_pin);
     if (h->first_dev) (void)hipFree(h->first_dev);
+    if (h->box_dev) (void)hipFree(h->box_dev);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -839,12 +848,20 @@ int sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk
     const bool bar = (cc.friction_barrier_weight > 0.0 || cc.bound_barrier_weight > 0.0) && model_id != SDDP_MODEL_LIP30;
     if (!model_dims(model_id, d, bar)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
     if (nk < 1 || !k || !x || !u || !p) return fail(nullptr, SDDP_ERR_ARG, "bad argument");
-    const DevConsts dc = make_dev_consts(cc);
+    DevConsts dc = make_dev_consts(cc);
     const int nz = d.nx + d.nu;
+    double* dbox = nullptr;
     const size_t D = sizeof(double);
     int* dk = nullptr;
     double *dx = nullptr, *du = nullptr, *dp = nullptr, *drec = nullptr, *df = nullptr, *dF = nullptr, *dH = nullptr, *dg = nullptr, *dL = nullptr;
 #define TRY0(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(nullptr, SDDP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+    if (bar) {
+        double hb[128];
+        for (int i = 0; i < 64; ++i) { hb[i] = cc.lower[i]; hb[64 + i] = cc.upper[i]; }
+        TRY0(hipMalloc((void**)&dbox, sizeof(hb)));
+        TRY0(hipMemcpy(dbox, hb, sizeof(hb), hipMemcpyHostToDevice));
+        dc.box = dbox;
+    }
     TRY0(hipMalloc((void**)&dk, nk * sizeof(int)));
     TRY0(hipMalloc((void**)&dx, size_t(nk) * d.nx * D));
     TRY0(hipMalloc((void**)&du, size_t(nk) * d.nu * D));
@@ -878,8 +895,9 @@ int sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk
     if (H_out) TRY0(hipMemcpy(H_out, dH, size_t(nk) * nz * nz * D, hipMemcpyDeviceToHost));
     if (g_out) TRY0(hipMemcpy(g_out, dg, size_t(nk) * nz * D, hipMemcpyDeviceToHost));
     if (L_out) TRY0(hipMemcpy(L_out, dL, size_t(nk) * D, hipMemcpyDeviceToHost));
-    void* bufs[] = {dk, dx, du, dp, drec, df, dF, dH, dg, dL};
-    for (void* b : bufs) (void)hipFree(b);
+    void* bufs[] = {dk, dx, du, dp, drec, df, dF, dH, dg, dL, dbox};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
 #undef TRY0
     return SDDP_OK;
 }

@@ -171,6 +171,16 @@ __device__ __forceinline__ void phase_derivs(const DevConsts& c, int N, const do
         for (int i = 0; i < M::NU; ++i) u[i] = us[ku * M::NU + i];
         M::derivs(c, x, u, P + k * M::NP, k, N, rec + size_t(k) * M::NREC);
     }
+    if (M::SO2) {   // full second-order builds: the factors of the wdot Hessian, stage knots only (a pass of its own: registers)
+        for (int k = lane; k < N; k += kWave) {
+            double x[M::NX], u[M::NU];
+#pragma unroll
+            for (int i = 0; i < M::NX; ++i) x[i] = xs[k * M::NX + i];
+#pragma unroll
+            for (int i = 0; i < M::NU; ++i) u[i] = us[k * M::NU + i];
+            M::so2_knot(c, x, u, P + k * M::NP, rec + size_t(k) * M::NREC);
+        }
+    }
 }
 
 // initial defects d_{k+1} = f(x_k,u_k) - x_{k+1}, total cost and defect 1-norm of the current iterate

@@ -31,7 +31,9 @@ struct DevConsts {
     double mu_lin, bar_w, bar_s;   // friction-cone exponential barrier (BAR models only): linearised coefficient, weight, sharpness
     int inertia_mode;
     double box_w, box_s;           // bound barrier (BAR models only, sddp.h): weight (0: off), sharpness
-    double lower[64], upper[64];   // ... bounds of z = [x u]; read with compile-time indices (scalar loads from the kernarg segment)
+    unsigned long long box_lm, box_um;   // ... bit j: z_j has a finite lower / upper bound
+    const double* box;             // ... device array lower[64] | upper[64] (a pointer, not 128 kernel-argument words: those are
+                                   //     loop-invariant scalar loads the compiler hoists and keeps live -- 3.9 KB of scratch)
 };
 
 inline DevConsts make_dev_consts(const sddp_model_consts& c) {
@@ -62,7 +64,12 @@ inline DevConsts make_dev_consts(const sddp_model_consts& c) {
     d.bar_s = c.friction_barrier_sharpness;
     d.box_w = c.bound_barrier_weight;
     d.box_s = c.bound_barrier_sharpness;
-    for (int i = 0; i < 64; ++i) { d.lower[i] = c.lower[i]; d.upper[i] = c.upper[i]; }
+    d.box_lm = d.box_um = 0;
+    for (int i = 0; i < 64; ++i) {
+        if (c.lower[i] > -1e300) d.box_lm |= 1ull << i;
+        if (c.upper[i] < 1e300) d.box_um |= 1ull << i;
+    }
+    d.box = nullptr;               // set by the caller that owns the device copy of the bounds (sddp_api.hip)
     return d;
 }
 
@@ -365,7 +372,7 @@ struct SrbdModel {
     }
 
     // opt-in barrier on the bounds of z = [x u] (BAR builds, sddp.h; ddp.py:203-208): w sum_j [exp(s (z_j - ub_j)) + exp(s (lb_j - z_j))]
-    // over the finite bounds.  Compile-time j: the bounds are scalar loads and the test for a finite bound a scalar branch.
+    // over the finite bounds.  Compile-time j: whether z_j is bounded is a bit test on a scalar, only bounded entries load and exp.
     // grad / hdiag (derivative phase): gradient added into grad[j], Gauss-Newton Hessian (w s^2 / 2) e of the residual form
     // r = sqrt(w) exp(s (z - ub) / 2) written to hdiag[j] (0 where unbounded)
     template <class XV, class UV>
@@ -377,8 +384,8 @@ struct SrbdModel {
             for (int j = 0; j < NZ; ++j) {
                 const double z = j < NX ? x[j < NX ? j : 0] : u[j < NX ? 0 : j - NX];
                 double eu = 0.0, el = 0.0;
-                if (c.upper[j] < 1e300) eu = exp(c.box_s * (z - c.upper[j]));
-                if (c.lower[j] > -1e300) el = exp(c.box_s * (c.lower[j] - z));
+                if ((c.box_um >> j) & 1) eu = exp(c.box_s * (z - c.box[64 + j]));
+                if ((c.box_lm >> j) & 1) el = exp(c.box_s * (c.box[j] - z));
                 L += eu + el;
                 if (grad) grad[j] += ws * (eu - el);
                 if (hdiag) hdiag[j] = k2 * (eu + el);
@@ -633,16 +640,10 @@ struct SrbdModel {
                     g[XCD + 3 * b + 1] += sp * ey; g[XCD + 3 * b + 4] -= sp * ey;
                 }
             }
-            if (BAR) {      // bound barrier (off: zeros): gradient into g, Gauss-Newton Hessian diagonal into the record
-                double hb[NZ];
-                (void)bound_cost(c, x, u, g, hb);
-#pragma unroll
-                for (int i = 0; i < NZ; ++i) rec[REC_BB + i] = hb[i];
-            }
+            if (BAR) (void)bound_cost(c, x, u, g, rec + REC_BB);   // bound barrier (off: zeros): gradient into g, GN Hessian diagonal into the record
 #pragma unroll
             for (int i = 0; i < NZ; ++i) rec[REC_G + i] = g[i];
-            if (SO2) so2_record(c, o, w, q, rec);       // last: A and the gradient are stored, only the core quantities are live
-            return;
+            return;                                     // (SO2 builds: the second-order factors are a pass of their own, so2_knot)
         }
 #pragma unroll
         for (int i = 0; i < NZ; ++i) rec[REC_G + i] = g[i];
@@ -670,6 +671,16 @@ struct SrbdModel {
         matvec3(d2M, q.wdot, t2);
 #pragma unroll
         for (int m = 0; m < 3; ++m) out[m] = cr[m] + t2[m];
+    }
+    // the second-order factors of one stage knot, as a pass of its own after derivs(): the accelerations are recomputed (a few
+    // hundred flops) so that this code does not share its registers with the first-derivative code (two-per-SIMD build: scratch)
+    __device__ __forceinline__ static void so2_knot(const DevConsts& c, const double* x, const double* u, const double* p, double* rec) {
+        if (!SO2) return;
+        double cp[NC][3], f[NC][3];
+        load_contacts(x, u, p, cp, f);
+        Core q;
+        core(c, x + XR, x + XO, x + XW, cp, f, q);
+        so2_record(c, x + XO, x + XW, q, rec);
     }
     __device__ __forceinline__ static void so2_record(const DevConsts& c, const double* o, const double* w, const Core& q, double* rec) {
         double dR[9], dM[9];
@@ -1148,6 +1159,7 @@ struct LipModel {
     static constexpr bool SO2 = false;
     __device__ __forceinline__ static void so2_prepare(const DevConsts&, const double*, const double*, double*, int, int) {}
     __device__ __forceinline__ static void so2_pair_code(int, int&, int&) {}
+    __device__ __forceinline__ static void so2_knot(const DevConsts&, const double*, const double*, const double*, double*) {}
     __device__ __forceinline__ static double p_cref(const double* p, int i) { return p[3 + 2 * i]; }
     __device__ __forceinline__ static double p_sw(const double* p, int i) { return p[4 + 2 * i]; }
 
