@@ -141,8 +141,10 @@ bool model_uses_mw(int model_id) {
 // only the kernel a model actually uses is instantiated
 using KernelFn = void (*)(SolveArgs);
 template <class M> KernelFn pick_solve(int waves_per_simd) {
-    if constexpr (use_mw<M>()) return solve_kernel_mw<M>;
-    else return waves_per_simd >= 2 ? solve_kernel_w2<M> : solve_kernel<M>;
+    if constexpr (use_mw<M>()) {
+        if constexpr (2 * LdsMW<M>::BYTES <= size_t(160) * 1024) return waves_per_simd >= 2 ? solve_kernel_mw_w2<M> : solve_kernel_mw<M>;
+        else return solve_kernel_mw<M>;
+    } else return waves_per_simd >= 2 ? solve_kernel_w2<M> : solve_kernel<M>;
 }
 template <class M> KernelFn pick_backward() { if constexpr (use_mw<M>()) return backward_kernel_mw<M>; else return backward_kernel<M>; }
 template <class M> KernelFn pick_forward() { if constexpr (use_mw<M>()) return forward_kernel_mw<M>; else return forward_kernel<M>; }
@@ -229,7 +231,7 @@ int launch_solve(sddp_handle* h, SolveArgs a, int first, int count) {
 // resident capacity over the builds a handle may switch between (sddp_set_options): sizes the work buffers
 template <class M>
 int max_slots(sddp_handle* h, int* slots) {
-    if constexpr (use_mw<M>()) return kernel_slots<M>(h, pick_solve<M>(1), slots);
+    if constexpr (use_mw<M>() && 2 * LdsMW<M>::BYTES > size_t(160) * 1024) return kernel_slots<M>(h, pick_solve<M>(1), slots);
     else {
         const int keep = h->opts.waves_per_simd;
         int s1 = 0, s2 = 0;

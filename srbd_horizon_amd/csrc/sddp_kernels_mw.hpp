@@ -832,6 +832,29 @@ __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
     }
 }
 
+// the same body capped at half the register file: two workgroups per CU where the tiles of two instances fit its LDS (lip30:
+// 2 x 77 KB); sddp_options.waves_per_simd = 2 picks it, results are identical
+template <class M>
+__global__ __launch_bounds__(kThreadsMW) __attribute__((amdgpu_waves_per_eu(2))) void solve_kernel_mw_w2(SolveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double s[];
+    int* q_pos = reinterpret_cast<int*>(s + LdsMW<M>::CTL + 15);
+    const int slot = blockIdx.x;
+    const bool queued = A.qhead != nullptr;
+    if (queued && threadIdx.x == 0) *q_pos = atomicAdd(A.qhead, 1);
+    __syncthreads();
+    int i = queued ? *q_pos : slot;
+    __syncthreads();
+    while (i < A.count) {
+        const int b = (queued && A.order) ? A.order[i] : A.first + i;
+        solve_instance_mw<M>(A, s, b, slot);
+        if (!queued) break;
+        if (threadIdx.x == 0) *q_pos = atomicAdd(A.qhead, 1);
+        __syncthreads();
+        i = *q_pos;
+        __syncthreads();
+    }
+}
+
 template <class M>
 __global__ __launch_bounds__(kThreadsMW) void backward_kernel_mw(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double s[];

@@ -119,6 +119,19 @@ def test_throughput_build_returns_the_same_results_as_the_latency_build():
     eng.set_initial_state(b37["x0"]); eng.set_x_warmstart(b37["xs"]); eng.set_u_warmstart(b37["us"])
     eng.solve(b37["params"])
     assert np.all(eng.stats["converged"] == 1)
+    # lip30: the tiles of TWO instances fit the LDS of a CU, so waves_per_simd = 2 selects the half-register-file build of the
+    # 4-wave kernel (two workgroups per CU); more instances than its slots: a queue.  Same results as the full-register build
+    bl = workload.make_batch("lip30", 20, np.arange(700))
+    rl = []
+    for w in (1, 2):
+        eng = DdpEngine("lip30", 20, 700, opts=dict(opts, waves_per_simd=w))
+        eng.set_initial_state(bl["x0"]); eng.set_x_warmstart(bl["xs"]); eng.set_u_warmstart(bl["us"])
+        x, u = eng.solve(bl["params"])
+        rl.append((x, u, eng.stats.copy(), eng.queue_info()))
+    np.testing.assert_array_equal(rl[0][2]["iters"], rl[1][2]["iters"])
+    np.testing.assert_allclose(rl[1][0], rl[0][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(rl[1][1], rl[0][1], rtol=0, atol=1e-9)
+    assert rl[1][3][1] == 2 * rl[0][3][1] and rl[0][3][2] == rl[1][3][2] == 700, (rl[0][3], rl[1][3])   # twice the resident workgroups, both queued
 
 
 def test_batches_in_flight_on_separate_streams_equal_sequential_solves():
