@@ -585,6 +585,8 @@ def single_instance_extras(N, opts, workload, DdpEngine):
     # dsrbd_example.py:30-31), cold start with open defects, one launch (one instance per CU resident, the rest queue)
     out["srbd37_n60_batch"] = mw_batch("srbd37", 60, 512, opts, workload, DdpEngine)
     out["srbd37_n20_batch"] = mw_batch("srbd37", 20, 1024, opts, workload, DdpEngine)
+    # BASELINE configs[0]'s model as a batch: the LIP tiles fit a CU's LDS twice, so two workgroups per CU (waves_per_simd = 2)
+    out["lip30_n20_batch"] = mw_batch("lip30", 20, 4096, dict(opts, waves_per_simd=2), workload, DdpEngine)
     return out
 
 
