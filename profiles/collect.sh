@@ -26,4 +26,4 @@ passes mw_srbd37_n60_ python3 profiles/run_mw_batch.py srbd37 60 512
 python3 bench.py --steps $STEPS --warmup 5 > $O/bench.log 2> $O/bench.err
 echo "bench done"
 python3 profiles/make_summary.py $R $O $STEPS | tee $O/summary.txt
-mkdir -p gpurun_out/profiles_$R && find profiles/$R -maxdepth 1 -type f -exec cp {} gpurun_out/profiles_$R/ ;
+mkdir -p gpurun_out/profiles_$R && find profiles/$R -maxdepth 1 -type f -exec cp {} gpurun_out/profiles_$R/ \;

@@ -6,7 +6,7 @@ rnd, O = sys.argv[1:3]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), rnd)
 os.makedirs(out_dir, exist_ok=True)
-one = lambda d, pat: sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))[0]
+one = lambda d, pat: max(glob.glob(os.path.join(d, "**", pat), recursive=True), key=os.path.getmtime)      # gpurun merges runs: newest
 last_json = lambda f: json.loads([l for l in open(f) if l.startswith("{")][-1])
 
 

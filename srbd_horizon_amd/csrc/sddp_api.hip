@@ -85,7 +85,7 @@ struct sddp_handle {
     KInfo kinfo[2];                 // per kernel build: dynamic-LDS attribute set, resident workgroups on this device
     int last_grid = 0, last_queued = 0;
     double* box_dev = nullptr;      // lower[64] | upper[64] of the bound barrier (barrier builds)
-    double* first_dev = nullptr;    // [B][nu + nx + 2] packed first knots of sddp_solve_resident_first, and its pinned host image
+    double* first_dev = nullptr;    // [B][nu + nx + 3] packed first knots of sddp_solve_resident_first, and its pinned host image
     double* first_pin = nullptr;
     char* up_pin = nullptr;         // pinned ring for small host->device uploads of the setters (no wait per call)
     size_t up_off = 0;
@@ -729,7 +729,7 @@ int sddp_solve_resident_first(sddp_handle* h, double* u0_out, double* x1_out, do
     if (!u0_out || !x1_out) return fail(h, SDDP_ERR_ARG, "NULL argument");
     rc = sddp_solve_device(h, h->P);
     if (rc != SDDP_OK) return rc;
-    const int w = h->d.nu + h->d.nx + 2;
+    const int w = h->d.nu + h->d.nx + 3;
     const size_t bytes = size_t(h->B) * w * sizeof(double);
     if (!h->first_dev) {
         HIP_TRY(h, hipMalloc((void**)&h->first_dev, bytes));
@@ -749,9 +749,8 @@ int sddp_solve_resident_first(sddp_handle* h, double* u0_out, double* x1_out, do
         std::memcpy(u0_out + size_t(b) * h->d.nu, r, h->d.nu * sizeof(double));
         std::memcpy(x1_out + size_t(b) * h->d.nx, r + h->d.nu, h->d.nx * sizeof(double));
         if (cost_out) cost_out[b] = r[h->d.nu + h->d.nx];
-        const int code = int(r[h->d.nu + h->d.nx + 1]);
-        if (iters_out) iters_out[b] = code & 0xffff;
-        if (status_out) status_out[b] = (code >> 16) & 0xff;
+        if (iters_out) iters_out[b] = int(r[h->d.nu + h->d.nx + 1]);
+        if (status_out) status_out[b] = int(r[h->d.nu + h->d.nx + 2]);
     }
     h->have_xws = true;
     return SDDP_OK;

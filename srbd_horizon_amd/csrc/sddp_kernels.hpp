@@ -1100,17 +1100,17 @@ __global__ __launch_bounds__(kWave) void forward_kernel(SolveArgs A) {
 }
 
 // what an MPC tick applies: the first input u_0 and the state the plan expects next, x_1, of every instance, packed
-// [B][nu + nx] (+ cost, iterations as two more doubles) for one small copy to the host instead of the whole trajectories
+// [B][nu + nx] (+ cost, iterations, status as three more doubles) for one small copy to the host instead of the whole trajectories
 __global__ __launch_bounds__(256) void first_knot_kernel(int N, int B, int nx, int nu, const double* __restrict__ xs,
                                                          const double* __restrict__ us, const sddp_stats* __restrict__ st,
                                                          double* __restrict__ out) {
-    const int w = nu + nx + 2;
+    const int w = nu + nx + 3;
     for (size_t e = size_t(blockIdx.x) * 256 + threadIdx.x; e < size_t(B) * w; e += size_t(gridDim.x) * 256) {
         const int b = int(e / w), j = int(e % w);
         double v;
         if (j < nu) v = us[size_t(b) * N * nu + j];
         else if (j < nu + nx) v = xs[(size_t(b) * (N + 1) + 1) * nx + (j - nu)];
-        else v = j == nu + nx ? st[b].cost : double(st[b].iters | (st[b].status << 16) | (st[b].converged << 24));
+        else v = j == nu + nx ? st[b].cost : (j == nu + nx + 1 ? double(st[b].iters) : double(st[b].status));
         out[e] = v;
     }
 }
