@@ -518,11 +518,11 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
                 M::so2_prepare(c, s + L::REC, s + L::VP, s + L::REC + L::SO2T, lane, kWave);
                 wave_sync();
             }
-            M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, SQ, theta, lane, kWave, s + L::REC + L::SO2T, ki + L::SO2L);
+            M::add_second_order(c, s + L::REC, s + L::VP, QFull{s + L::Q, SQ}, theta, lane, kWave, s + L::REC + L::SO2T, ki + L::SO2L);
             wave_sync();
         }
         if (M::BAR) {         // friction-cone barrier builds: its Hessian blocks on the force-force diagonal of Q
-            M::add_barrier(s + L::REC, s + L::Q, SQ, lane, kWave, M::SO2 ? theta : 0.0);
+            M::add_barrier(s + L::REC, QFull{s + L::Q, SQ}, lane, kWave, M::SO2 ? theta : 0.0);
             wave_sync();
         }
         SDDP_TICK(4)

@@ -40,14 +40,29 @@ struct LdsMW {
     // row strides (doubles), all == 2 (mod 4); row counts padded to the block shapes (pad rows stay zero)
     static constexpr int SV = pad2mod4(NX), RV = round_up(NX, imax(LW, 2));     // VXX [RV][SV]
     static constexpr int SI = pad2mod4(imax(NI, SV)), RZ = round_up(NZ, 3);     // FT, WT [RZ][SI]
-    static constexpr int SQ = pad2mod4(NZ), RQ = round_up(NZ, 2);               // Q [RQ][SQ]
+    static constexpr int SQ = pad2mod4(NZ);                                     // QU [NU][SQ]; the diagonal tables [SQ]
     static constexpr int SK = pad2mod4(NU);                                     // KT [NX][SK]: KT[c][i] = K[i][c]
     static constexpr int RPW = (NU + kWavesMW - 1) / kWavesMW;                  // Gauss-Jordan rows per wave
     static constexpr int NSTG = M::NREC + M::NP + NX;                           // staged knot: record | params | defect
     static constexpr int NRECP = (((M::NREC + 1) & ~1) + M::NSO2T + 1) & ~1, NPP = (M::NP + 1) & ~1;   // record + second-order factors (SO2)
     static constexpr int SO2T = (M::NREC + 1) & ~1;
     static constexpr int SG = (NX + 1) & ~1;                                    // staged gain rows in the forward pass
-    static constexpr int VXX = 0;
+    // ---- tables of the kernel: they survive the forward pass
+    static constexpr int DS = 0;                       // constant diagonal, state part [SQ]
+    static constexpr int DG = DS + SQ;                 // constant diagonal, stage part [SQ]
+    static constexpr int LS = DG + SQ;                 // extra-row weights, state / stage [NE] each
+    static constexpr int LG = LS + ((NE + 1) & ~1);
+    static constexpr int CTL = LG + ((NE + 1) & ~1);   // control words shared by the 4 waves [16]
+    static constexpr int DUMP = CTL + 16;              // where the model code's writes to the unstored (x row, u column) part of Q go
+    static constexpr int KI = DUMP + 2;                // ints: dkind[SQ], dci[SQ], block LUTs of Q and Vxx
+    static constexpr int SO2L = 2 * SQ + NTRIQ + NTRIV;          // SO2 builds: pair codes of the second-order contraction
+    static constexpr int KI_INTS = SO2L + M::NSO2L;
+    static constexpr int WORK = KI + ((KI_INTS + 1) / 2 + 1) / 2 * 2;
+    // ---- work tiles of the sweep; the forward pass aliases ALL of them (restore_tiles_mw rebuilds what the sweep relies on).
+    // Q is not a tile of its own (two workgroups must fit a CU's 160 KB): its state block Qxx is written INTO the Vxx tile --
+    // Vxx_{k+1} is dead once W = (V~ F~)^T is formed, and Vxx_k = Qxx + Qux^T K then updates the tile in place -- its input rows
+    // [Qux | Quu] are the QU tile, and the (state row, input column) block, the transpose of Qux, is not stored at all.
+    static constexpr int VXX = WORK;
     static constexpr int FT = VXX + RV * SV;
     static constexpr int VX = FT + RZ * SI;
     static constexpr int VP = VX + SV;
@@ -55,30 +70,25 @@ struct LdsMW {
     static constexpr int REC = QV + SQ;
     static constexpr int PK = REC + NRECP;
     static constexpr int DK = PK + NPP;                 // [SV], pad zero
-    static constexpr int KT = DK + SV;
-    static constexpr int KF = KT + NX * SK;            // kff [SK]
-    static constexpr int GT = KF + SK;                 // Gauss-Jordan hand-off rows, double buffered [2][RPW][64]
-    static constexpr int DS = GT + 2 * RPW * kWave;    // constant diagonal, state part [SQ]
-    static constexpr int DG = DS + SQ;                 // constant diagonal, stage part [SQ]
-    static constexpr int LS = DG + SQ;                 // extra-row weights, state / stage [NE] each
-    static constexpr int LG = LS + ((NE + 1) & ~1);
-    static constexpr int CTL = LG + ((NE + 1) & ~1);   // control words shared by the 4 waves [16]
-    static constexpr int KI = CTL + 16;                // ints: dkind[SQ], dci[SQ], block LUTs of Q and Vxx
-    static constexpr int SO2L = 2 * SQ + NTRIQ + NTRIV;          // SO2 builds: pair codes of the second-order contraction
-    static constexpr int KI_INTS = SO2L + M::NSO2L;
-    static constexpr int WT = KI + ((KI_INTS + 1) / 2 + 1) / 2 * 2;
-    static constexpr int Q = WT + RZ * SI;
-    // forward pass: per-lane vector columns X | Y | U and the staged gains of one knot alias WT and Q (and may run past Q)
-    static constexpr int RO_X = WT, RO_Y = RO_X + NX * kWave, RO_U = RO_Y + NX * kWave, RO_G = RO_U + NU * kWave;
+    static constexpr int KF = DK + SV;                  // kff [SK]
+    static constexpr int WT = KF + SK;
+    // the gain tile and the Gauss-Jordan hand-off rows live where WT is dead (after the Q phase, until the next knot's W phase)
+    static constexpr int KT = WT;                       // KT [NX][SK]: KT[c][i] = K[i][c]
+    static constexpr int GT = KT + ((NX * SK + 1) & ~1);   // hand-off rows, double buffered [2][RPW][64]
+    static_assert(GT + 2 * RPW * kWave <= WT + RZ * SI, "gain tile + hand-off rows fit the dead WT tile");
+    static constexpr int QU = WT + RZ * SI;             // [NU][SQ]: row i = row NX + i of Q (columns: state | input)
+    static constexpr int SWEEP_END = QU + NU * SQ;
+    // forward pass: per-lane vector columns X | Y | U and the staged gains of one knot
+    static constexpr int RO_X = WORK, RO_Y = RO_X + NX * kWave, RO_U = RO_Y + NX * kWave, RO_G = RO_U + NU * kWave;
     static constexpr int RO_K = RO_G + ((NU + 1) & ~1);                        // kff [NU] | K [NU][SG]
     // knot operands staged beside the gains, double buffered: x_k [SG] | u_k [NUE] | d_k [SG] | p_k [NPE]
     static constexpr int NUE = (NU + 1) & ~1, NPE = (M::NP + 1) & ~1;
     static constexpr int SB_X = 0, SB_U = SG, SB_D = SB_U + NUE, SB_P = SB_D + SG, SB_N = SB_P + NPE;
     static constexpr int RO_S = RO_K + NU * SG;
     static constexpr int RO_END = RO_S + 2 * SB_N;
-    static constexpr int TOTAL = imax(Q + RQ * SQ, RO_END);
+    static constexpr int TOTAL = imax(SWEEP_END, RO_END);
     static constexpr size_t BYTES = size_t(TOTAL) * sizeof(double);
-    static_assert((FT | VX | VP | QV | REC | PK | DK | KT | KF | GT | DS | DG | LS | LG | CTL | KI | WT | Q | RO_G) % 2 == 0, "16-byte aligned sections");
+    static_assert((FT | VX | VP | QV | REC | PK | DK | KT | KF | GT | DS | DG | LS | LG | CTL | KI | WORK | WT | QU | RO_G) % 2 == 0, "16-byte aligned sections");
 };
 
 // C[i][j] += sum_m A[i][m] B[j][m], m < DEPTH (even): RA x RB register block, rows read two fp64 at a time (ds_read_b128).
@@ -126,12 +136,18 @@ __device__ __forceinline__ void pin_regs(double (&v)[NN]) {
     for (int i = 0; i < NN; ++i) asm volatile("" : "+v"(v[i]));
 }
 
+// The work tiles in the state the sweep relies on: everything zero (pad rows and columns of the tiles are summed over), then the
+// constant part of F~^T (F_entry on a zero record).  At the start of a solve and after every forward pass, which uses the whole
+// work area for its per-lane columns.  zero_work_mw by any group of threads, a barrier, ft_constants_mw by all, a barrier.
 template <class M>
-__device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
+__device__ __forceinline__ void zero_work_mw(double* s, int t, int nthreads) {
     using L = LdsMW<M>;
-    constexpr int NX = M::NX, NZ = M::NZ, NE = M::NE, NEV = M::NEV;
-    for (int e = tid; e < L::TOTAL; e += kThreadsMW) s[e] = 0.0;    // also: zero record -> constant part of F below
-    __syncthreads();
+    for (int e = L::WORK + t; e < L::TOTAL; e += nthreads) s[e] = 0.0;
+}
+template <class M>
+__device__ void ft_constants_mw(const DevConsts& c, double* s, int tid) {
+    using L = LdsMW<M>;
+    constexpr int NX = M::NX, NZ = M::NZ, NEV = M::NEV;
     for (int e = tid; e < NZ * NX; e += kThreadsMW) {
         const int j = e / NX, i = e % NX;
         s[L::FT + j * L::SI + i] = M::F_entry(c, s + L::REC, i, j);
@@ -140,6 +156,17 @@ __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
         const int j = e / NEV, m = e % NEV;
         s[L::FT + j * L::SI + NX + m] = M::E_const(c, m, j);
     }
+}
+
+template <class M>
+__device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
+    using L = LdsMW<M>;
+    constexpr int NX = M::NX, NZ = M::NZ, NE = M::NE, NEV = M::NEV;
+    for (int e = tid; e < L::WORK; e += kThreadsMW) s[e] = 0.0;
+    zero_work_mw<M>(s, tid, kThreadsMW);
+    __syncthreads();
+    ft_constants_mw<M>(c, s, tid);
+    __syncthreads();
     int* ki = reinterpret_cast<int*>(s + L::KI);
     for (int i = tid; i < NZ; i += kThreadsMW) {
         s[L::DS + i] = M::dg_state(c, i);
@@ -197,6 +224,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
     static_assert(NCOL <= kWave, "one lane per augmented column");
     const int lane = tid & (kWave - 1), wave = tid / kWave;
     const int* ki = reinterpret_cast<const int*>(s + L::KI);
+    const QSplit<NX> qm{s + L::VXX, SV, s + L::QU, SQ, s + L::DUMP};   // Q as the model code addresses it (LdsMW)
     double g1_acc = 0.0, g2_acc = 0.0, dv_acc = 0.0, qu_acc = 0.0;   // per-wave partial sums, combined after the sweep
     dV1 = G1 = G2 = qu_inf = 0.0;
     auto stage_word = [&](int k, int w) -> double {    // [0,NREC) record | [NREC,NREC+NP) parameters | then the defect
@@ -266,12 +294,15 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             for (int jj = 0; jj < L::JW; ++jj)
 #pragma unroll
                 for (int ll = 0; ll < L::LW; ++ll)
-                    if (j0 + jj < NZ && l0 + ll < NX) s[L::WT + (j0 + jj) * SI + l0 + ll] = acc[jj][ll];
+                    if (l0 + ll < NX) s[L::WT + (j0 + jj) * SI + l0 + ll] = acc[jj][ll];    // pad rows of F~^T are zero: so is acc
         }
-        for (int e = tid; e < NZ * NEV; e += kThreadsMW) {
-            const int j = e / NEV, m = e % NEV;
-            const double lam = state * s[L::LS + m] + s[L::LG + m];
-            s[L::WT + j * SI + NX + m] = lam * s[L::FT + j * SI + NX + m];
+        // the whole tile is rewritten at every knot, pad columns included: the gain tile and the Gauss-Jordan hand-off rows of
+        // the knot before live in it (LdsMW), and a pad holding a non-finite left-over of a failed solve must not meet a zero
+        for (int e = tid; e < L::RZ * (SI - NX); e += kThreadsMW) {
+            const int j = e / (SI - NX), m = e % (SI - NX);
+            double v = 0.0;
+            if (m < NEV && j < NZ) v = (state * s[L::LS + m] + s[L::LG + m]) * s[L::FT + j * SI + NX + m];
+            s[L::WT + j * SI + NX + m] = v;
         }
         __syncthreads();
         SDDP_TICK(3)
@@ -297,13 +328,19 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                     for (int j = 0; j < i; ++j) { const double off = 0.5 * (acc[i][j] + acc[j][i]); acc[i][j] = acc[j][i] = off; }
                 }
             }
+            // state rows go into the Vxx tile (dead since the W phase; both triangles: the Vxx update reads whole 2x2 blocks),
+            // input rows into QU (both triangles of Quu: the solve reads whole rows), (state row, input column) is not stored
+            auto put = [&](int r, int cc, double v) {
+                if (r >= NX) s[L::QU + (r - NX) * SQ + cc] = v;
+                else if (cc < NX) s[L::VXX + r * SV + cc] = v;
+            };
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     if (a0 + i < NZ && b0 + j < NZ) {
-                        s[L::Q + (a0 + i) * SQ + b0 + j] = acc[i][j];
-                        if (a0 != b0) s[L::Q + (b0 + j) * SQ + a0 + i] = acc[i][j];
+                        put(a0 + i, b0 + j, acc[i][j]);
+                        if (a0 != b0) put(b0 + j, a0 + i, acc[i][j]);
                     }
         }
         SDDP_TICK(13)
@@ -325,12 +362,12 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 M::so2_prepare(c, s + L::REC, s + L::VP, s + L::REC + L::SO2T, tid, kThreadsMW);
                 __syncthreads();
             }
-            M::add_second_order(c, s + L::REC, s + L::VP, s + L::Q, SQ, theta, tid, kThreadsMW, s + L::REC + L::SO2T,
+            M::add_second_order(c, s + L::REC, s + L::VP, qm, theta, tid, kThreadsMW, s + L::REC + L::SO2T,
                                 reinterpret_cast<const int*>(s + L::KI) + L::SO2L);
             __syncthreads();
         }
         if (M::BAR) {         // friction-cone barrier builds: its Hessian blocks on the force-force diagonal of Q
-            M::add_barrier(s + L::REC, s + L::Q, SQ, tid, kThreadsMW, M::SO2 ? theta : 0.0);
+            M::add_barrier(s + L::REC, qm, tid, kThreadsMW, M::SO2 ? theta : 0.0);
             __syncthreads();
         }
         SDDP_TICK(4)
@@ -342,7 +379,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int i = wave * RPW + r, ic = i < NU ? i : NU - 1;
-                double v = s[L::Q + (NX + ic) * SQ + qcol];
+                double v = s[L::QU + ic * SQ + qcol];
                 const double qv = s[L::QV + NX + ic];
                 v = lane == NU ? qv : v;
                 v += (i == lane) ? mu : 0.0;
@@ -422,7 +459,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         if (wave == kLast && lane < NX) {
             double acc = s[L::QV + lane], qr[NU], kv[NU];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) { qr[i] = s[L::Q + lane * SQ + NX + i]; kv[i] = s[L::KF + i]; }
+            for (int i = 0; i < NU; ++i) { qr[i] = s[L::QU + i * SQ + lane]; kv[i] = s[L::KF + i]; }     // Qxu[lane][i] = Qux[i][lane]
             pin_regs(qr);
             pin_regs(kv);
 #pragma unroll
@@ -436,17 +473,17 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             double v00 = 0, v01 = 0, v10 = 0, v11 = 0;
 #pragma unroll 4
             for (int i = 0; i < NU; ++i) {
-                const double qa = s[L::Q + a0 * SQ + NX + i], qb = s[L::Q + a1 * SQ + NX + i];
+                const double qa = s[L::QU + i * SQ + a0], qb = s[L::QU + i * SQ + a1];
                 const double kc = s[L::KT + c0 * SK + i], kd = s[L::KT + c1 * SK + i];
                 v00 = fma(qa, kc, v00);
                 v01 = fma(qa, kd, v01);
                 v10 = fma(qb, kc, v10);
                 v11 = fma(qb, kd, v11);
             }
-            v00 += s[L::Q + a0 * SQ + c0];
-            v01 += s[L::Q + a0 * SQ + c1];
-            v10 += s[L::Q + a1 * SQ + c0];
-            v11 += s[L::Q + a1 * SQ + c1];
+            v00 += s[L::VXX + a0 * SV + c0];         // Qxx sits in the tile it is about to become (in place: a thread reads only
+            v01 += s[L::VXX + a0 * SV + c1];         // the block it owns; the mirrored stores below go to blocks above the
+            v10 += s[L::VXX + a1 * SV + c0];         // diagonal, which no thread reads here)
+            v11 += s[L::VXX + a1 * SV + c1];
             if (a0 == c0) { const double off = 0.5 * (v01 + v10); v01 = v10 = off; }
             const bool ha = a0 + 1 < NX, hc = c0 + 1 < NX;
             s[L::VXX + a0 * SV + c0] = v00;
@@ -480,7 +517,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
 }
 
 // forward pass on 4 waves (called by every thread): lane l of every wave works on step length alpha_l.
-// Returns the cost of lane l's trajectory in wave 0 (other waves: unspecified).  Clobbers the WT and Q tiles.
+// Returns the cost of lane l's trajectory in wave 0 (other waves: unspecified).  Clobbers the whole work area of LdsMW (zero_work_mw / ft_constants_mw put it back).
 // Per knot: (A) wave 0 closes the previous knot, (B) every wave computes its rows of the feedback law, (C) wave 0 steps the
 // model while the other waves fetch the next knot's operands (gains, x_k, u_k, d_k, p_k: coalesced loads into LDS, read back
 // as broadcasts) and write the stored lane's x_k / u_k to HBM.
@@ -647,13 +684,6 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
     return J;
 }
 
-// re-zero what the forward pass clobbered and the sweep relies on: the WT tile (its pad columns / rows are summed over)
-template <class M>
-__device__ __forceinline__ void restore_tiles_mw(double* s, int tid) {
-    using L = LdsMW<M>;
-    for (int e = tid; e < L::RZ * L::SI; e += kThreadsMW) s[L::WT + e] = 0.0;
-}
-
 // fused persistent solve, 4 waves per instance
 template <class M>
 __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s, const int b, const int slot) {
@@ -700,7 +730,9 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
         while (iters < o.max_iters) {
             SDDP_TICK(9)
             if (wave == 0) phase_derivs<M>(A.c, N, xs, us, P, rec, lane);
-            restore_tiles_mw<M>(s, tid);
+            else zero_work_mw<M>(s, tid - kWave, kThreadsMW - kWave);      // the forward pass used the whole work area
+            __syncthreads();
+            ft_constants_mw<M>(A.c, s, tid);
             __syncthreads();
             SDDP_TICK(0)
             double dV1, G1, G2, qu_inf, a_win = 0.0, J_win = 0.0;
@@ -760,7 +792,13 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
                 }
                 if (!accepted && theta != 0.0) {   // fall back to the plain Gauss-Newton sweep once
                     theta = 0.0;
-                    if (tiles_dirty) { __syncthreads(); restore_tiles_mw<M>(s, tid); __syncthreads(); }
+                    if (tiles_dirty) {
+                        __syncthreads();
+                        zero_work_mw<M>(s, tid, kThreadsMW);
+                        __syncthreads();
+                        ft_constants_mw<M>(A.c, s, tid);
+                        __syncthreads();
+                    }
                     continue;
                 }
                 break;

@@ -227,6 +227,23 @@ __device__ __forceinline__ void world_inertia_d2(const DevConsts& c, const doubl
     }
 }
 
+// Q as the model code sees it: a symmetric (NZ x NZ) matrix addressed by (row, column).  The single-wavefront kernel stores it
+// whole (QFull).  The 4-wavefront kernel (QSplit) keeps the state block inside its Vxx tile, the input rows [Qux | Quu] as a tile
+// of their own and does not store the (state row, input column) block at all: accesses to it go to a dump word.
+struct QFull {
+    double* q; int ld;
+    __device__ __forceinline__ double& at(int r, int c) const { return q[r * ld + c]; }
+};
+template <int NXS>
+struct QSplit {
+    double* xx; int ldx; double* u; int ldu; double* dump;
+    __device__ __forceinline__ double& at(int r, int c) const {
+        double* pu = u + (r - NXS) * ldu + c;
+        double* px = c < NXS ? xx + r * ldx + c : dump;
+        return *(r >= NXS ? pu : px);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // SRBD family.  CS=false, NC=2: srbd13 (metric model, contacts are parameters);  CS=true, NC=4: srbd37
 // (reference problem, contacts are states -- prb.py:32-68).
@@ -1066,8 +1083,9 @@ struct SrbdModel {
              (so << 22) | (c1 << 24) | (bar << 26);
     }
 
-    __device__ __forceinline__ static void add_second_order(const DevConsts& c, const double* rec, const double* vp, double* Q,
-                                                            int NZP, double theta, int lane, int nlanes, const double* tmp = nullptr,
+    template <class QM>
+    __device__ __forceinline__ static void add_second_order(const DevConsts& c, const double* rec, const double* vp, QM Q,
+                                                            double theta, int lane, int nlanes, const double* tmp = nullptr,
                                                             const int* lut = nullptr) {
         if (SO2) {
             // full term (second_order = 2): Q += theta * (sum_m lam_m d2 wdot_m + dt v'_o . d2 odot), lam = dt v'_w + 2 gq wdot: the
@@ -1092,7 +1110,7 @@ struct SrbdModel {
                 const double g10 = g1[0], g11 = g1[1], g12 = g1[2], g20 = g2[0], g21 = g2[1], g22 = g2[2];
                 const double a10 = rec[REC_A + colb], a11 = rec[REC_A + NA + colb], a12 = rec[REC_A + 2 * NA + colb];
                 const double a20 = rec[REC_A + cola], a21 = rec[REC_A + NA + cola], a22 = rec[REC_A + 2 * NA + cola];
-                double q0 = Q[row * NZP + col];
+                double q0 = Q.at(row, col);
                 const double cf = c1 == 0 ? -1.0 : (c1 == 1 ? c.lever : -c.lever);
                 double sv = cf * t1 - t2;
                 sv -= m1 ? (g10 * a10 + g11 * a11 + g12 * a12) : 0.0;
@@ -1100,8 +1118,8 @@ struct SrbdModel {
                 double val = theta * sv + (so == 0 ? 0.0 : (so == 1 ? 0.5 : -0.5) * theta * c.dt * vo);
                 if (bar) val += theta * barrier_h(rec + REC_B + 5 * (i2f >> 4), (i2f >> 2) & 3, i2f & 3);
                 q0 += val;
-                Q[row * NZP + col] = q0;
-                if (row != col) Q[col * NZP + row] = q0;     // Q is symmetric here: both triangles hold the same value
+                Q.at(row, col) = q0;
+                if (row != col) Q.at(col, row) = q0;     // Q is symmetric here: both triangles hold the same value
             }
             return;
         }
@@ -1114,32 +1132,33 @@ struct SrbdModel {
             const int row = NX + uf(i) + a, col = isc ? XC + 3 * i + b : XR + b;
             // every operand (and the two Q entries to update) requested before the first use: one LDS round trip, not five
             double v0 = vp[XW], v1 = vp[XW + 1], v2 = vp[XW + 2], m0 = mi[0], m1 = mi[1], m2 = mi[2];
-            double q0 = Q[row * NZP + col], q1 = Q[col * NZP + row];
+            double q0 = Q.at(row, col), q1 = Q.at(col, row);
             asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(m0), "+v"(m1), "+v"(m2), "+v"(q0), "+v"(q1));
             const double l0 = c.dt * v0, l1 = c.dt * v1, l2 = c.dt * v2;
             const double y = m0 * l0 + m1 * l1 + m2 * l2;
             const int d = (b - a + 3) % 3;                                // 2: +y , 1: -y , 0: diagonal (zero)
             const double sk = d == 2 ? y : (d == 1 ? -y : 0.0);
             const double val = theta * c.lever * (isc ? sk : -sk);
-            Q[row * NZP + col] = q0 + val;
-            Q[col * NZP + row] = q1 + val;
+            Q.at(row, col) = q0 + val;
+            Q.at(col, row) = q1 + val;
         }
     }
 
     // BAR builds: the barrier's Gauss-Newton Hessian blocks (3x3 per contact force, from the record) added to Quu
     // ... and the diagonal of the bound barrier; so2_theta (SO2 builds: theta of this sweep, else 0): its exact Hessian is twice the
     // Gauss-Newton one, like the friction barrier's (whose share is added in add_second_order)
-    __device__ __forceinline__ static void add_barrier(const double* rec, double* Q, int ld, int lane, int nlanes, double so2_theta = 0.0) {
+    template <class QM>
+    __device__ __forceinline__ static void add_barrier(const double* rec, QM Q, int lane, int nlanes, double so2_theta = 0.0) {
         for (int e = lane; e < 9 * NC + NZ; e += nlanes) {      // every entry of Q is updated by exactly one lane
             if (e < 9 * NC) {
                 const int i = e / 9, a = (e % 9) / 3, b = e % 3, j = NX + uf(i) + a;
                 double v = barrier_h(rec + REC_B + 5 * i, a, b);
                 if (a == b) v += (1.0 + so2_theta) * rec[REC_BB + j];          // the force diagonals take their bound term here
-                Q[j * ld + NX + uf(i) + b] += v;
+                Q.at(j, NX + uf(i) + b) += v;
             } else {
                 const int j = e - 9 * NC;
                 const bool force = j >= NX && (!CS || (j - NX) % 6 >= 3);
-                if (!force) Q[j * ld + j] += (1.0 + so2_theta) * rec[REC_BB + j];
+                if (!force) Q.at(j, j) += (1.0 + so2_theta) * rec[REC_BB + j];
             }
         }
     }
@@ -1152,7 +1171,7 @@ struct SrbdModel {
 struct LipModel {
     static constexpr int NC = 4;
     static constexpr bool BAR = false;
-    __device__ __forceinline__ static void add_barrier(const double*, double*, int, int, int, double = 0.0) {}
+    template <class QM> __device__ __forceinline__ static void add_barrier(const double*, QM, int, int, double = 0.0) {}
     static constexpr int NX = 30, NU = 15, NZ = 45, NP = 11;
     static constexpr int XR = 0, XC = 3, XRD = 15, XCD = 18;
     static constexpr int REC_G = 0, NREC = NZ, NSO2T = 0, NSO2L = 0;
@@ -1420,7 +1439,8 @@ struct LipModel {
     __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int) {}
     __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int, int, double* = nullptr,
                                                       const double* = nullptr) {}
-    __device__ __forceinline__ static void add_second_order(const DevConsts&, const double*, const double*, double*, int, double, int, int,
+    template <class QM>
+    __device__ __forceinline__ static void add_second_order(const DevConsts&, const double*, const double*, QM, double, int, int,
                                                             const double* = nullptr, const int* = nullptr) {}
 
 };
