@@ -138,21 +138,21 @@ __device__ __forceinline__ void pin_regs(double (&v)[NN]) {
 
 // The work tiles in the state the sweep relies on: everything zero (pad rows and columns of the tiles are summed over), then the
 // constant part of F~^T (F_entry on a zero record).  At the start of a solve and after every forward pass, which uses the whole
-// work area for its per-lane columns.  zero_work_mw by any group of threads, a barrier, ft_constants_mw by all, a barrier.
+// work area for its per-lane columns.  zero_work_mw by a group of threads, a barrier, ft_constants_mw by a group, a barrier.
 template <class M>
 __device__ __forceinline__ void zero_work_mw(double* s, int t, int nthreads) {
     using L = LdsMW<M>;
     for (int e = L::WORK + t; e < L::TOTAL; e += nthreads) s[e] = 0.0;
 }
 template <class M>
-__device__ void ft_constants_mw(const DevConsts& c, double* s, int tid) {
+__device__ void ft_constants_mw(const DevConsts& c, double* s, int t, int nthreads) {
     using L = LdsMW<M>;
     constexpr int NX = M::NX, NZ = M::NZ, NEV = M::NEV;
-    for (int e = tid; e < NZ * NX; e += kThreadsMW) {
+    for (int e = t; e < NZ * NX; e += nthreads) {
         const int j = e / NX, i = e % NX;
         s[L::FT + j * L::SI + i] = M::F_entry(c, s + L::REC, i, j);
     }
-    for (int e = tid; e < NZ * NEV; e += kThreadsMW) {
+    for (int e = t; e < NZ * NEV; e += nthreads) {
         const int j = e / NEV, m = e % NEV;
         s[L::FT + j * L::SI + NX + m] = M::E_const(c, m, j);
     }
@@ -165,7 +165,7 @@ __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
     for (int e = tid; e < L::WORK; e += kThreadsMW) s[e] = 0.0;
     zero_work_mw<M>(s, tid, kThreadsMW);
     __syncthreads();
-    ft_constants_mw<M>(c, s, tid);
+    ft_constants_mw<M>(c, s, tid, kThreadsMW);
     __syncthreads();
     int* ki = reinterpret_cast<int*>(s + L::KI);
     for (int i = tid; i < NZ; i += kThreadsMW) {
@@ -247,6 +247,25 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
     // the block this thread owns in the Q / Vxx phases never changes: read the LUTs once per sweep
     const int code_q = tid < L::NTRIQ ? ki[2 * SQ + tid] : 0;
     const int code_v = tid < L::NTRIV ? ki[2 * SQ + L::NTRIQ + tid] : 0;
+    // where the 3x3 block of Q goes (LdsMW: state rows inside the Vxx tile, input rows in QU, (state row, input column) nowhere):
+    // row offsets and one validity bit per element, for the block itself (d) and for its mirror image (m), once per sweep
+    int q_off_d[3], q_off_m[3];
+    unsigned q_ok_d = 0, q_ok_m = 0;
+    {
+        const int a0 = 3 * (code_q >> 8), b0 = 3 * (code_q & 255);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int rd = a0 + i, rm = b0 + i;
+            q_off_d[i] = (rd >= NX ? L::QU + (rd - NX) * SQ : L::VXX + rd * SV) + b0;
+            q_off_m[i] = (rm >= NX ? L::QU + (rm - NX) * SQ : L::VXX + rm * SV) + a0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int cd = b0 + j, cm = a0 + j;
+                if (rd < NZ && cd < NZ && (rd >= NX || cd < NX)) q_ok_d |= 1u << (3 * i + j);               // element (a0+i, b0+j)
+                if (a0 != b0 && rm < NZ && cm < NZ && (rm >= NX || cm < NX)) q_ok_m |= 1u << (3 * i + j);   // element (b0+i, a0+j)
+            }
+        }
+    }
     static_assert(L::NTRIQ <= kThreadsMW && L::NTRIV <= kThreadsMW, "one block per thread");
     double r_stage[RS];
 #pragma unroll
@@ -296,13 +315,20 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 for (int ll = 0; ll < L::LW; ++ll)
                     if (l0 + ll < NX) s[L::WT + (j0 + jj) * SI + l0 + ll] = acc[jj][ll];    // pad rows of F~^T are zero: so is acc
         }
-        // the whole tile is rewritten at every knot, pad columns included: the gain tile and the Gauss-Jordan hand-off rows of
-        // the knot before live in it (LdsMW), and a pad holding a non-finite left-over of a failed solve must not meet a zero
-        for (int e = tid; e < L::RZ * (SI - NX); e += kThreadsMW) {
-            const int j = e / (SI - NX), m = e % (SI - NX);
-            double v = 0.0;
-            if (m < NEV && j < NZ) v = (state * s[L::LS + m] + s[L::LG + m]) * s[L::FT + j * SI + NX + m];
-            s[L::WT + j * SI + NX + m] = v;
+        // the gain tile and the Gauss-Jordan hand-off rows of the knot before live in this tile (LdsMW): every entry they can
+        // have touched is rewritten here, pad columns included -- a non-finite left-over of a failed solve must not meet a zero
+        constexpr int NPADC = SI - NX - NEV;                                        // pad columns of a row
+        constexpr int NPADR = (L::GT + 2 * RPW * kWave - L::WT + SI - 1) / SI;      // rows the knot before has written over
+        for (int e = tid; e < NZ * NEV + NPADR * NPADC; e += kThreadsMW) {
+            if (e < NZ * NEV) {
+                const int j = e / NEV, m = e % NEV;
+                const double lam = state * s[L::LS + m] + s[L::LG + m];
+                s[L::WT + j * SI + NX + m] = lam * s[L::FT + j * SI + NX + m];
+            } else {
+                const int q = e - NZ * NEV;
+                constexpr int D = NPADC > 0 ? NPADC : 1;
+                s[L::WT + (q / D) * SI + NX + NEV + q % D] = 0.0;
+            }
         }
         __syncthreads();
         SDDP_TICK(3)
@@ -330,18 +356,13 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             }
             // state rows go into the Vxx tile (dead since the W phase; both triangles: the Vxx update reads whole 2x2 blocks),
             // input rows into QU (both triangles of Quu: the solve reads whole rows), (state row, input column) is not stored
-            auto put = [&](int r, int cc, double v) {
-                if (r >= NX) s[L::QU + (r - NX) * SQ + cc] = v;
-                else if (cc < NX) s[L::VXX + r * SV + cc] = v;
-            };
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    if (a0 + i < NZ && b0 + j < NZ) {
-                        put(a0 + i, b0 + j, acc[i][j]);
-                        if (a0 != b0) put(b0 + j, a0 + i, acc[i][j]);
-                    }
+                for (int j = 0; j < 3; ++j) {
+                    if ((q_ok_d >> (3 * i + j)) & 1u) s[q_off_d[i] + j] = acc[i][j];
+                    if ((q_ok_m >> (3 * j + i)) & 1u) s[q_off_m[j] + i] = acc[i][j];      // (b0+j, a0+i)
+                }
         }
         SDDP_TICK(13)
         if (wave == kLast) {
@@ -473,7 +494,8 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             double v00 = 0, v01 = 0, v10 = 0, v11 = 0;
 #pragma unroll 4
             for (int i = 0; i < NU; ++i) {
-                const double qa = s[L::QU + i * SQ + a0], qb = s[L::QU + i * SQ + a1];
+                const double2_t q2 = lds2(s + L::QU + i * SQ + a0);       // Qux[i][a0], Qux[i][a0 + 1]: a0 is even, so are SQ and QU
+                const double qa = q2.x, qb = q2.y;                        // (odd NX, last block: qb is a finite neighbour, not stored)
                 const double kc = s[L::KT + c0 * SK + i], kd = s[L::KT + c1 * SK + i];
                 v00 = fma(qa, kc, v00);
                 v01 = fma(qa, kd, v01);
@@ -729,10 +751,13 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
     else
         while (iters < o.max_iters) {
             SDDP_TICK(9)
+            const bool work_dirty = iters > 0 || o.initial_rollout;        // a forward pass used the whole work area:
+            if (work_dirty) {                                              // zero it, then the constants of F~^T by waves 1..3
+                zero_work_mw<M>(s, tid, kThreadsMW);                       // while wave 0 (one lane per knot) differentiates
+                __syncthreads();
+            }
             if (wave == 0) phase_derivs<M>(A.c, N, xs, us, P, rec, lane);
-            else zero_work_mw<M>(s, tid - kWave, kThreadsMW - kWave);      // the forward pass used the whole work area
-            __syncthreads();
-            ft_constants_mw<M>(A.c, s, tid);
+            else if (work_dirty) ft_constants_mw<M>(A.c, s, tid - kWave, kThreadsMW - kWave);
             __syncthreads();
             SDDP_TICK(0)
             double dV1, G1, G2, qu_inf, a_win = 0.0, J_win = 0.0;
@@ -796,7 +821,7 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
                         __syncthreads();
                         zero_work_mw<M>(s, tid, kThreadsMW);
                         __syncthreads();
-                        ft_constants_mw<M>(A.c, s, tid);
+                        ft_constants_mw<M>(A.c, s, tid, kThreadsMW);
                         __syncthreads();
                     }
                     continue;
