@@ -390,7 +390,7 @@ def mw_batch(model, N, B, opts, workload, DdpEngine, reps=3):
     ab = algorithmic_bytes(N, nx, nu, npar, iters, roll, B)
     flop_it = N * (sweep_flops_per_knot(nx, nu) + 2.0 * (nx * nu + nx * nx) + 6.0 * (nx + nu) ** 2)   # sweep + one rollout + model eval (approx.)
     slots, grid, queued = e.queue_info()
-    return {"solves_per_s": B / min(wall), "kernel_solves_per_s": B / (kms * 1e-3), "batch": B, "horizon_N": N, "mean_iters": float(np.mean(iters)),
+    return {"waves_per_simd": int(opts.get("waves_per_simd", 1)), "solves_per_s": B / min(wall), "kernel_solves_per_s": B / (kms * 1e-3), "batch": B, "horizon_N": N, "mean_iters": float(np.mean(iters)),
             "max_iters": int(iters.max()), "mean_rollouts": float(np.mean(roll)), "converged_frac": float(np.mean(st["converged"] == 1)),
             "slots": slots, "grid": grid, "kernel": f"solve_kernel_mw<{model}>", "kernel_ms": kms,
             "algorithmic_bytes": ab, "achieved_gbs": ab / (kms * 1e-3) / 1e9, "hbm_frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -582,11 +582,14 @@ def single_instance_extras(N, opts, workload, DdpEngine):
             "solve_median": float(np.median(lp.solve_ms[10:])), "mean_iters": float(np.mean(its[10:])),
             "cpu": cpu_tick_baseline(mname, traced(mname, ns, nt)[10:], its[10:])}
     # the 4-wavefront kernel as a batch: BASELINE configs[4] (srbd37, N = 60) and the reference's own problem (srbd37, ns = 20,
-    # dsrbd_example.py:30-31), cold start with open defects, one launch (one instance per CU resident, the rest queue)
-    out["srbd37_n60_batch"] = mw_batch("srbd37", 60, 512, opts, workload, DdpEngine)
-    out["srbd37_n20_batch"] = mw_batch("srbd37", 20, 1024, opts, workload, DdpEngine)
-    # BASELINE configs[0]'s model as a batch: the LIP tiles fit a CU's LDS twice, so two workgroups per CU (waves_per_simd = 2)
-    out["lip30_n20_batch"] = mw_batch("lip30", 20, 4096, dict(opts, waves_per_simd=2), workload, DdpEngine)
+    # dsrbd_example.py:30-31), cold start with open defects, one launch.  Two workgroups per CU (waves_per_simd = 2: 512 slots,
+    # the tiles of two instances fit a CU's LDS since round 3), four queue rounds per launch; the one-per-CU build beside it
+    w2 = dict(opts, waves_per_simd=2)
+    out["srbd37_n60_batch"] = mw_batch("srbd37", 60, 1024, w2, workload, DdpEngine)
+    out["srbd37_n20_batch"] = mw_batch("srbd37", 20, 2048, w2, workload, DdpEngine)
+    out["srbd37_n20_batch_one_workgroup_per_cu"] = mw_batch("srbd37", 20, 1024, opts, workload, DdpEngine)
+    # BASELINE configs[0]'s model as a batch
+    out["lip30_n20_batch"] = mw_batch("lip30", 20, 4096, w2, workload, DdpEngine)
     return out
 
 

@@ -54,8 +54,8 @@ struct LdsMW {
     static constexpr int LG = LS + ((NE + 1) & ~1);
     static constexpr int CTL = LG + ((NE + 1) & ~1);   // control words shared by the 4 waves [16]
     static constexpr int DUMP = CTL + 16;              // where the model code's writes to the unstored (x row, u column) part of Q go
-    static constexpr int KI = DUMP + 2;                // ints: dkind[SQ], dci[SQ], block LUTs of Q and Vxx
-    static constexpr int SO2L = 2 * SQ + NTRIQ + NTRIV;          // SO2 builds: pair codes of the second-order contraction
+    static constexpr int KI = DUMP + 2;                // ints: dkind[SQ], dci[SQ]
+    static constexpr int SO2L = 2 * SQ;                          // SO2 builds: pair codes of the second-order contraction
     static constexpr int KI_INTS = SO2L + M::NSO2L;
     static constexpr int WORK = KI + ((KI_INTS + 1) / 2 + 1) / 2 * 2;
     // ---- work tiles of the sweep; the forward pass aliases ALL of them (restore_tiles_mw rebuilds what the sweep relies on).
@@ -136,6 +136,14 @@ __device__ __forceinline__ void pin_regs(double (&v)[NN]) {
     for (int i = 0; i < NN; ++i) asm volatile("" : "+v"(v[i]));
 }
 
+// t-th block of a lower triangle, row-major: (block row << 8) | block column, row >= column.  A thread owns the same block of Q
+// (and of Vxx) for the whole kernel and decodes it once per sweep.
+__device__ __forceinline__ int tri_code(int t) {
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= t) ++a;
+    return (a << 8) | (t - a * (a + 1) / 2);
+}
+
 // The work tiles in the state the sweep relies on: everything zero (pad rows and columns of the tiles are summed over), then the
 // constant part of F~^T (F_entry on a zero record).  At the start of a solve and after every forward pass, which uses the whole
 // work area for its per-lane columns.  zero_work_mw by a group of threads, a barrier, ft_constants_mw by a group, a barrier.
@@ -178,12 +186,6 @@ __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
         s[L::LS + m] = M::lam_state(c, m);
         s[L::LG + m] = M::lam_stage(c, m);
     }
-    for (int t = tid; t < L::NTRIQ + L::NTRIV; t += kThreadsMW) {   // t -> (block row << 8) | block column, row >= column
-        const int tt = t < L::NTRIQ ? t : t - L::NTRIQ;
-        int a = 0;
-        while ((a + 1) * (a + 2) / 2 <= tt) ++a;
-        ki[2 * L::SQ + t] = (a << 8) | (tt - a * (a + 1) / 2);
-    }
     for (int e = tid; e < M::NSO2L / 2; e += kThreadsMW) M::so2_pair_code(e, ki[L::SO2L + 2 * e], ki[L::SO2L + 2 * e + 1]);
     __syncthreads();
 }
@@ -194,7 +196,7 @@ template <class M>
 __device__ void mw_const_block(const DevConsts& c, const double* s, int tid, double (&qconst)[3][3]) {
     using L = LdsMW<M>;
     const int* ki = reinterpret_cast<const int*>(s + L::KI);
-    const int code = tid < L::NTRIQ ? ki[2 * L::SQ + tid] : 0;
+    const int code = tid < L::NTRIQ ? tri_code(tid) : 0;
     const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -244,9 +246,9 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         if (a == b) v += s[L::DS + a] + M::dparam(c, s + L::PK, ki[a], ki[SQ + a], 1.0, 0.0);
         s[L::VXX + a * SV + b] = v;
     }
-    // the block this thread owns in the Q / Vxx phases never changes: read the LUTs once per sweep
-    const int code_q = tid < L::NTRIQ ? ki[2 * SQ + tid] : 0;
-    const int code_v = tid < L::NTRIV ? ki[2 * SQ + L::NTRIQ + tid] : 0;
+    // the block this thread owns in the Q / Vxx phases never changes: decoded once per sweep
+    const int code_q = tid < L::NTRIQ ? tri_code(tid) : 0;
+    const int code_v = tid < L::NTRIV ? tri_code(tid) : 0;
     // where the 3x3 block of Q goes (LdsMW: state rows inside the Vxx tile, input rows in QU, (state row, input column) nowhere):
     // row offsets and one validity bit per element, for the block itself (d) and for its mirror image (m), once per sweep
     int q_off_d[3], q_off_m[3];

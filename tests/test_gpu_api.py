@@ -132,6 +132,19 @@ def test_throughput_build_returns_the_same_results_as_the_latency_build():
     np.testing.assert_allclose(rl[1][0], rl[0][0], rtol=0, atol=1e-9)
     np.testing.assert_allclose(rl[1][1], rl[0][1], rtol=0, atol=1e-9)
     assert rl[1][3][1] == 2 * rl[0][3][1] and rl[0][3][2] == rl[1][3][2] == 700, (rl[0][3], rl[1][3])   # twice the resident workgroups, both queued
+    # srbd37 since round 3 (Q without a tile of its own: 77 KB per instance): the same, on a queue longer than its 512 slots
+    bs = workload.make_batch("srbd37", 20, np.arange(600))
+    rs = []
+    for w in (1, 2):
+        eng = DdpEngine("srbd37", 20, 600, opts=dict(opts, waves_per_simd=w, queue_order=2))
+        eng.set_initial_state(bs["x0"]); eng.set_x_warmstart(bs["xs"]); eng.set_u_warmstart(bs["us"])
+        x, u = eng.solve(bs["params"])
+        rs.append((x, u, eng.stats.copy(), eng.queue_info()))
+    np.testing.assert_array_equal(rs[0][2]["iters"], rs[1][2]["iters"])
+    np.testing.assert_array_equal(rs[0][2]["status"], rs[1][2]["status"])
+    np.testing.assert_allclose(rs[1][0], rs[0][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(rs[1][1], rs[0][1], rtol=0, atol=1e-9)
+    assert rs[1][3][1] == 2 * rs[0][3][1] == 512 and rs[0][3][2] == rs[1][3][2] == 600, (rs[0][3], rs[1][3])
 
 
 def test_batches_in_flight_on_separate_streams_equal_sequential_solves():
