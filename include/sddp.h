@@ -54,11 +54,13 @@ typedef struct sddp_options {
                                            selects its own kernel build at sddp_create */
     int    waves_per_simd;              /* scheduling hint, no effect on results.  1 (default): the kernel build with the full
                                            register file per instance -- shortest time for ONE batch.  2: the build capped at
-                                           half the register file, two instances resident per SIMD -- highest solves/s when
-                                           several batches are in flight on separate streams.  Only the
-                                           one-wavefront-per-instance kernel (srbd13) has both builds. */
+                                           half the register file, two instances resident per SIMD (srbd13) or two workgroups
+                                           per CU (the 4-wavefront kernel of srbd37 / lip30, whose tiles fit a CU's LDS twice)
+                                           -- highest solves/s for queues of many instances.  A build
+                                           whose tiles do not fit twice (srbd37 with barrier + second_order 2) runs as with 1. */
     int    queue_order;                 /* scheduling hint, no effect on results.  A solve launch runs on the workgroups that are
-                                           resident on the device at once ("slots": 256 CUs x 4 SIMDs x waves_per_simd for srbd13);
+                                           resident on the device at once ("slots": 256 CUs x 4 SIMDs x waves_per_simd for srbd13,
+                                           256 CUs x waves_per_simd for srbd37 / lip30);
                                            a batch with more instances than slots is a work queue the slots pull from.  A launch ends
                                            with its slowest instance, so the slow ones should start first:
                                            1 (default): longest PREVIOUS solve first -- the queue is ordered by the iteration count of
