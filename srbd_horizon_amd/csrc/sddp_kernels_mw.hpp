@@ -13,8 +13,11 @@
 //   * Every wave keeps an identical copy of the scalar solver state (cost, merit weight, regularisation, counters); values
 //     produced by one wave only reach the others through the control words CTL[..] behind a workgroup barrier.
 //
-// These models need > 48 KB of LDS per instance (<= 2 workgroups per CU), so the 4 waves do not fight the register budget
-// that rules this mapping out for srbd13 at four instances per CU (experiment log).
+//   * LDS: 75.7 KB (srbd37) / 45 KB (lip30) per instance, so that two workgroups share a CU (solve_kernel_mw_w2); Q has no
+//     tile of its own -- see LdsMW.
+//
+// These models need > 40 KB of LDS per instance (<= 2 workgroups per CU at 256 registers), so the 4 waves do not fight the
+// register budget that rules this mapping out for srbd13 at four instances per CU (experiment log).
 // Same device model code, same arithmetic up to summation order, same parity tests as the single-wavefront kernel.
 #pragma once
 #include "sddp_kernels.hpp"
@@ -58,7 +61,7 @@ struct LdsMW {
     static constexpr int SO2L = 2 * SQ;                          // SO2 builds: pair codes of the second-order contraction
     static constexpr int KI_INTS = SO2L + M::NSO2L;
     static constexpr int WORK = KI + ((KI_INTS + 1) / 2 + 1) / 2 * 2;
-    // ---- work tiles of the sweep; the forward pass aliases ALL of them (restore_tiles_mw rebuilds what the sweep relies on).
+    // ---- work tiles of the sweep; the forward pass aliases ALL of them (zero_work_mw / ft_constants_mw put back what the sweep relies on).
     // Q is not a tile of its own (two workgroups must fit a CU's 160 KB): its state block Qxx is written INTO the Vxx tile --
     // Vxx_{k+1} is dead once W = (V~ F~)^T is formed, and Vxx_k = Qxx + Qux^T K then updates the tile in place -- its input rows
     // [Qux | Quu] are the QU tile, and the (state row, input column) block, the transpose of Qux, is not stored at all.
