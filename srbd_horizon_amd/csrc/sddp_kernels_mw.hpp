@@ -33,7 +33,7 @@ __host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 
 template <class M>
 struct LdsMW {
-    static constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NEV = M::NEV, NI = NX + NEV;   // product rows only
+    static constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NEV = M::NEV;
     // register-block shapes: W = (V~F~)^T in JW x LW blocks, Q in 3x3 lower-triangle blocks, Vxx in 2x2 lower-triangle blocks
     static constexpr int JW = 3;
     static constexpr int LW = (round_up(NZ, 3) / 3) * (round_up(NX, 3) / 3) <= kThreadsMW ? 3 : 4;
@@ -42,7 +42,9 @@ struct LdsMW {
     static constexpr int NBV = round_up(NX, 2) / 2, NTRIV = NBV * (NBV + 1) / 2;
     // row strides (doubles), all == 2 (mod 4); row counts padded to the block shapes (pad rows stay zero)
     static constexpr int SV = pad2mod4(NX), RV = round_up(NX, imax(LW, 2));     // VXX [RV][SV]
-    static constexpr int SI = pad2mod4(imax(NI, SV)), RZ = round_up(NZ, 3);     // FT, WT [RZ][SI]
+    static constexpr int RZ = round_up(NZ, 3);                                  // WT [RZ][SV], FC / WC [RZ][SC]
+    static constexpr int ND = M::ND, SC = pad2mod4(ND + NEV);                   // compact columns: dense rows of F | variable extra rows
+    static constexpr int TBL = round_up(RZ, 2);                                 // per-column tables (pad rows: zero)
     static constexpr int SQ = pad2mod4(NZ);                                     // QU [NU][SQ]; the diagonal tables [SQ]
     static constexpr int SK = pad2mod4(NU);                                     // KT [NX][SK]: KT[c][i] = K[i][c]
     static constexpr int RPW = (NU + kWavesMW - 1) / kWavesMW;                  // Gauss-Jordan rows per wave
@@ -57,17 +59,24 @@ struct LdsMW {
     static constexpr int LG = LS + ((NE + 1) & ~1);
     static constexpr int CTL = LG + ((NE + 1) & ~1);   // control words shared by the 4 waves [16]
     static constexpr int DUMP = CTL + 16;              // where the model code's writes to the unstored (x row, u column) part of Q go
-    static constexpr int KI = DUMP + 2;                // ints: dkind[SQ], dci[SQ]
-    static constexpr int SO2L = 2 * SQ;                          // SO2 builds: pair codes of the second-order contraction
+    static constexpr int BET = DUMP + 2;               // sparsity of [fx fu] by column z (M::nbr): entry beta[z] in row nbi[z] ...
+    static constexpr int IDC = BET + TBL;              // ... and 1.0 where the identity entry is not part of a dense row [TBL] each
+    static constexpr int KI = IDC + TBL;               // ints: dkind[SQ], dci[SQ], nbi[TBL]
+    static constexpr int NBI = 2 * SQ;
+    static constexpr int SO2L = NBI + TBL;                       // SO2 builds: pair codes of the second-order contraction
     static constexpr int KI_INTS = SO2L + M::NSO2L;
     static constexpr int WORK = KI + ((KI_INTS + 1) / 2 + 1) / 2 * 2;
     // ---- work tiles of the sweep; the forward pass aliases ALL of them (zero_work_mw / ft_constants_mw put back what the sweep relies on).
     // Q is not a tile of its own (two workgroups must fit a CU's 160 KB): its state block Qxx is written INTO the Vxx tile --
     // Vxx_{k+1} is dead once W = (V~ F~)^T is formed, and Vxx_k = Qxx + Qux^T K then updates the tile in place -- its input rows
     // [Qux | Quu] are the QU tile, and the (state row, input column) block, the transpose of Qux, is not stored at all.
+    // F~^T is kept COMPACT: FC[z] = (F[D_d][z], d < ND | E[m][z], m < NEV) -- everything of column z that is not the identity or
+    // its one neighbour entry (M::nbr); WT = (Vxx F)^T dense over the NX next-state columns, WC the same compact columns of
+    // (V~ F~)^T (dense-row columns of WT duplicated | lambda_m E[m][z]).  The products run over the compact index (depth
+    // ND + NEV instead of NX + NEV) plus two single terms per row.
     static constexpr int VXX = WORK;
-    static constexpr int FT = VXX + RV * SV;
-    static constexpr int VX = FT + RZ * SI;
+    static constexpr int FC = VXX + RV * SV;
+    static constexpr int VX = FC + RZ * SC;
     static constexpr int VP = VX + SV;
     static constexpr int QV = VP + SV;
     static constexpr int REC = QV + SQ;
@@ -78,8 +87,8 @@ struct LdsMW {
     // the gain tile and the Gauss-Jordan hand-off rows live where WT is dead (after the Q phase, until the next knot's W phase)
     static constexpr int KT = WT;                       // KT [NX][SK]: KT[c][i] = K[i][c]
     static constexpr int GT = KT + ((NX * SK + 1) & ~1);   // hand-off rows, double buffered [2][RPW][64]
-    static_assert(GT + 2 * RPW * kWave <= WT + RZ * SI, "gain tile + hand-off rows fit the dead WT tile");
-    static constexpr int QU = WT + RZ * SI;             // [NU][SQ]: row i = row NX + i of Q (columns: state | input)
+    static constexpr int WC = imax(WT + RZ * SV, GT + 2 * RPW * kWave);      // (small models: the tile is sized by what it hosts)
+    static constexpr int QU = WC + RZ * SC;             // [NU][SQ]: row i = row NX + i of Q (columns: state | input)
     static constexpr int SWEEP_END = QU + NU * SQ;
     // forward pass: per-lane vector columns X | Y | U and the staged gains of one knot
     static constexpr int RO_X = WORK, RO_Y = RO_X + NX * kWave, RO_U = RO_Y + NX * kWave, RO_G = RO_U + NU * kWave;
@@ -91,7 +100,7 @@ struct LdsMW {
     static constexpr int RO_END = RO_S + 2 * SB_N;
     static constexpr int TOTAL = imax(SWEEP_END, RO_END);
     static constexpr size_t BYTES = size_t(TOTAL) * sizeof(double);
-    static_assert((FT | VX | VP | QV | REC | PK | DK | KT | KF | GT | DS | DG | LS | LG | CTL | KI | WORK | WT | QU | RO_G) % 2 == 0, "16-byte aligned sections");
+    static_assert((FC | VX | VP | QV | REC | PK | DK | KT | KF | GT | DS | DG | LS | LG | CTL | BET | IDC | KI | WORK | WT | WC | QU | RO_G) % 2 == 0, "16-byte aligned sections");
 };
 
 // C[i][j] += sum_m A[i][m] B[j][m], m < DEPTH (even): RA x RB register block, rows read two fp64 at a time (ds_read_b128).
@@ -130,6 +139,18 @@ __device__ __forceinline__ void dot_block(const double* A, int lda, const double
     for (int u = 0; u < REM; ++u) mac(u);
 }
 
+// NN consecutive doubles of a row; even NN: the address is 16-byte aligned (callers: even row strides, even offsets)
+template <int NN>
+__device__ __forceinline__ void load_run(const double* p, double (&v)[NN]) {
+    if constexpr (NN % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < NN; i += 2) { const double2_t t = lds2(p + i); v[i] = t.x; v[i + 1] = t.y; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NN; ++i) v[i] = p[i];
+    }
+}
+
 // Pins an array of loaded values: every element must be in its register here, so all the reads that produce them are issued
 // (in flight together) before the first use.  Left alone, the scheduler of these long straight-line phases issues each LDS read
 // just before its use: one exposed round trip per element (tools/isa_wait_batches.py shows them).
@@ -158,14 +179,10 @@ __device__ __forceinline__ void zero_work_mw(double* s, int t, int nthreads) {
 template <class M>
 __device__ void ft_constants_mw(const DevConsts& c, double* s, int t, int nthreads) {
     using L = LdsMW<M>;
-    constexpr int NX = M::NX, NZ = M::NZ, NEV = M::NEV;
-    for (int e = t; e < NZ * NX; e += nthreads) {
-        const int j = e / NX, i = e % NX;
-        s[L::FT + j * L::SI + i] = M::F_entry(c, s + L::REC, i, j);
-    }
-    for (int e = t; e < NZ * NEV; e += nthreads) {
-        const int j = e / NEV, m = e % NEV;
-        s[L::FT + j * L::SI + NX + m] = M::E_const(c, m, j);
+    constexpr int NZ = M::NZ, NEV = M::NEV, ND = M::ND;
+    for (int e = t; e < NZ * (ND + NEV); e += nthreads) {
+        const int j = e / (ND + NEV), q = e % (ND + NEV);
+        s[L::FC + j * L::SC + q] = q < ND ? M::F_entry(c, s + L::REC, M::dense_row(q), j) : M::E_const(c, q - ND, j);
     }
 }
 
@@ -184,6 +201,7 @@ __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
         s[L::DG + i] = M::dg_stage(c, i);
         ki[i] = M::dkind(i);
         ki[L::SQ + i] = M::dci(i);
+        M::nbr(c, i, ki[L::NBI + i], s[L::BET + i], s[L::IDC + i]);
     }
     for (int m = tid; m < NE; m += kThreadsMW) {
         s[L::LS + m] = M::lam_state(c, m);
@@ -222,7 +240,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
     using L = LdsMW<M>;
     constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NEV = M::NEV, NREC = M::NREC, NP = M::NP;
     static_assert(!M::CONST_ROWS_STATE_WEIGHTED, "constant rows must have node-independent weights");
-    constexpr int SV = L::SV, SI = L::SI, SQ = L::SQ, SK = L::SK, NSTG = L::NSTG, RPW = L::RPW;
+    constexpr int SV = L::SV, SC = L::SC, ND = L::ND, SQ = L::SQ, SK = L::SK, NSTG = L::NSTG, RPW = L::RPW;
     constexpr int NCOL = NU + 1 + NX;
     constexpr int RS = (NSTG + kThreadsMW - 1) / kThreadsMW;
     constexpr int kLast = kWavesMW - 1;
@@ -245,7 +263,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
     for (int e = tid; e < NX * NX; e += kThreadsMW) {
         const int a = e / NX, b = e % NX;
         double v = 0.0;
-        for (int m = 0; m < NEV; ++m) v += s[L::LS + m] * s[L::FT + a * SI + NX + m] * s[L::FT + b * SI + NX + m];
+        for (int m = 0; m < NEV; ++m) v += s[L::LS + m] * s[L::FC + a * SC + ND + m] * s[L::FC + b * SC + ND + m];
         if (a == b) v += s[L::DS + a] + M::dparam(c, s + L::PK, ki[a], ki[SQ + a], 1.0, 0.0);
         s[L::VXX + a * SV + b] = v;
     }
@@ -294,7 +312,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         const double state = k >= 1 ? 1.0 : 0.0;
         // ---- waves 0..2: variable entries of F~^T ; last wave: v' = Vx + Vxx d and the gap terms
         if (wave != kLast) {
-            M::expand_var(c, s + L::REC, s + L::FT, SI, tid, kThreadsMW - kWave);
+            M::template expand_var<true>(c, s + L::REC, s + L::FC, SC, tid, kThreadsMW - kWave);
         } else if (lane < NX) {
             double acc = 0.0;
 #pragma unroll 2
@@ -309,31 +327,64 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         }
         __syncthreads();
         SDDP_TICK(2)
-        // ---- WT = (V~ F~)^T : JW x LW register blocks over the NX dynamics rows ; extra rows are a scaling of F~^T
+        // ---- WT = (Vxx F)^T, JW x LW register blocks: row z = idc(z) Vxx[z] + beta(z) Vxx[n(z)] + sum_d F[D_d][z] Vxx[D_d] (the
+        // column sparsity of F, M::nbr); the columns that are dense rows of F also go into the compact tile WC
         for (int blk = tid; blk < L::NJB * L::NLB; blk += kThreadsMW) {
-            const int j0 = L::JW * (blk % L::NJB), l0 = L::LW * (blk / L::NJB);
-            double acc[L::JW][L::LW] = {};
-            dot_block<L::JW, L::LW, SV>(s + L::FT + j0 * SI, SI, s + L::VXX + l0 * SV, SV, acc);   // Vxx pad column is zero
+            constexpr int JW = L::JW, LW = L::LW;
+            const int j0 = JW * (blk % L::NJB), l0 = LW * (blk / L::NJB);
+            double acc[JW][LW];
+            {   // the two single terms of every row first: their operands are dead before the dense rows are requested
+                double idc[JW], bet[JW], va[JW][LW], vb[JW][LW];
 #pragma unroll
-            for (int jj = 0; jj < L::JW; ++jj)
+                for (int jj = 0; jj < JW; ++jj) {
+                    const int z = j0 + jj, zc = z < NX ? z : 0, nb = ki[L::NBI + z];      // pad rows: zero tables, zero FC row
+                    idc[jj] = s[L::IDC + z];
+                    bet[jj] = s[L::BET + z];
+                    load_run<LW>(s + L::VXX + zc * SV + l0, va[jj]);
+                    load_run<LW>(s + L::VXX + nb * SV + l0, vb[jj]);
+                }
 #pragma unroll
-                for (int ll = 0; ll < L::LW; ++ll)
-                    if (l0 + ll < NX) s[L::WT + (j0 + jj) * SI + l0 + ll] = acc[jj][ll];    // pad rows of F~^T are zero: so is acc
-        }
-        // the gain tile and the Gauss-Jordan hand-off rows of the knot before live in this tile (LdsMW): every entry they can
-        // have touched is rewritten here, pad columns included -- a non-finite left-over of a failed solve must not meet a zero
-        constexpr int NPADC = SI - NX - NEV;                                        // pad columns of a row
-        constexpr int NPADR = (L::GT + 2 * RPW * kWave - L::WT + SI - 1) / SI;      // rows the knot before has written over
-        for (int e = tid; e < NZ * NEV + NPADR * NPADC; e += kThreadsMW) {
-            if (e < NZ * NEV) {
-                const int j = e / NEV, m = e % NEV;
-                const double lam = state * s[L::LS + m] + s[L::LG + m];
-                s[L::WT + j * SI + NX + m] = lam * s[L::FT + j * SI + NX + m];
-            } else {
-                const int q = e - NZ * NEV;
-                constexpr int D = NPADC > 0 ? NPADC : 1;
-                s[L::WT + (q / D) * SI + NX + NEV + q % D] = 0.0;
+                for (int jj = 0; jj < JW; ++jj) { pin_regs(va[jj]); pin_regs(vb[jj]); }
+#pragma unroll
+                for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+                    for (int ll = 0; ll < LW; ++ll) acc[jj][ll] = fma(bet[jj], vb[jj][ll], idc[jj] * va[jj][ll]);
             }
+            if (ND > 0) {   // dense rows of F: row D_d of Vxx and column d of the compact tile, one step ahead
+                double vd[2][LW], fd[2][JW];
+                auto load_d = [&](int d, int buf) {
+                    load_run<LW>(s + L::VXX + M::dense_row(d) * SV + l0, vd[buf]);
+#pragma unroll
+                    for (int jj = 0; jj < JW; ++jj) fd[buf][jj] = s[L::FC + (j0 + jj) * SC + d];
+                };
+                load_d(0, 0);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    if (d + 1 < ND) load_d(d + 1, (d + 1) & 1);
+                    pin_regs(vd[d & 1]);
+                    pin_regs(fd[d & 1]);
+#pragma unroll
+                    for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+                        for (int ll = 0; ll < LW; ++ll) acc[jj][ll] = fma(fd[d & 1][jj], vd[d & 1][ll], acc[jj][ll]);
+                }
+            }
+#pragma unroll
+            for (int ll = 0; ll < LW; ++ll) {
+                const int l = l0 + ll, wc = M::dense_col(l < NX ? l : 0);
+                if (l < NX) {
+#pragma unroll
+                    for (int jj = 0; jj < JW; ++jj) {
+                        s[L::WT + (j0 + jj) * SV + l] = acc[jj][ll];
+                        if (wc >= 0) s[L::WC + (j0 + jj) * SC + wc] = acc[jj][ll];
+                    }
+                }
+            }
+        }
+        for (int e = tid; e < NZ * NEV; e += kThreadsMW) {    // extra rows: a scaling of F~^T
+            const int j = e / NEV, m = e % NEV;
+            const double lam = state * s[L::LS + m] + s[L::LG + m];
+            s[L::WC + j * SC + ND + m] = lam * s[L::FC + j * SC + ND + m];
         }
         __syncthreads();
         SDDP_TICK(3)
@@ -342,7 +393,24 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             const int code = code_q;
             const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
             double acc[3][3] = {};
-            dot_block<3, 3, SI>(s + L::FT + a0 * SI, SI, s + L::WT + b0 * SI, SI, acc);
+            {   // the two single terms of every row a0 + i against rows b0 + j of WT first (dead before the product's operand ring)
+                double idc[3], bet[3], wa[3][3], wb[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int z = a0 + i, zc = z < NX ? z : 0, nb = ki[L::NBI + z];
+                    idc[i] = s[L::IDC + z];
+                    bet[i] = s[L::BET + z];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { wa[i][j] = s[L::WT + (b0 + j) * SV + zc]; wb[i][j] = s[L::WT + (b0 + j) * SV + nb]; }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { pin_regs(wa[i]); pin_regs(wb[i]); }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][j] = fma(bet[i], wb[i][j], idc[i] * wa[i][j]);
+            }
+            dot_block<3, 3, SC>(s + L::FC + a0 * SC, SC, s + L::WC + b0 * SC, SC, acc);
             if (NEV < NE) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
@@ -372,12 +440,10 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         SDDP_TICK(13)
         if (wave == kLast) {
             for (int j = lane; j < NZ; j += kWave) {
-                double acc = s[L::REC + M::REC_G + j];
-#pragma unroll 2
-                for (int m = 0; m < SV; m += 2) {
-                    const double2_t f = lds2(s + L::FT + j * SI + m), v = lds2(s + L::VP + m);
-                    acc = fma(f.y, (m + 1 < NX) ? v.y : 0.0, fma(f.x, (m < NX) ? v.x : 0.0, acc));
-                }
+                const int zc = j < NX ? j : 0, nb = ki[L::NBI + j];
+                double acc = s[L::REC + M::REC_G + j] + fma(s[L::BET + j], s[L::VP + nb], s[L::IDC + j] * s[L::VP + zc]);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) acc = fma(s[L::FC + j * SC + d], s[L::VP + M::dense_row(d)], acc);
                 s[L::QV + j] = acc;
             }
         }

@@ -796,6 +796,31 @@ struct SrbdModel {
         return (i == j ? 1.0 : 0.0) + c.dt * s;
     }
 
+    // Sparsity of [fx fu] by COLUMN z (the 4-wavefront kernel's products run over it): besides the identity, column z has
+    // entries only in the ND = 7 "dense" next-state rows -- o (4) and w (3), where every per-knot variable entry lives -- and in
+    // at most ONE other row (F_entry): rdot_a -> r_a (dt), cdot_i,a -> c_i,a (dt), cddot_i,a -> cdot_i,a (dt), f_i,a -> rdot_a
+    // (dt / m).  So for any X indexed by the next state:  (F^T X)[z] = idc(z) X[z] + beta(z) X[n(z)] + sum_d F[D_d][z] X[D_d].
+    static constexpr int ND = 7;
+    __device__ __forceinline__ static constexpr int dense_row(int d) { return d < 4 ? XO + d : XW + (d - 4); }
+    // compact column of next-state row `row` (dense rows: 0..6) or of extra row `row - NX` (ND + m); -1 for any other row
+    __device__ __forceinline__ static constexpr int dense_col(int row) {
+        return row >= NX ? ND + (row - NX) : (row >= XO && row < XO + 4 ? row - XO : (row >= XW && row < XW + 3 ? 4 + (row - XW) : -1));
+    }
+    // column z: idc = 1 when the identity entry is not part of a dense row, (n, beta) = the one other row and its entry (0, 0: none)
+    __device__ static void nbr(const DevConsts& c, int z, int& n, double& beta, double& idc) {
+        int cls, ci, ax;
+        decode(z, cls, ci, ax);
+        idc = (z < NX && cls != V_O && cls != V_W) ? 1.0 : 0.0;
+        n = 0; beta = 0.0;
+        switch (cls) {
+            case V_RD: n = XR + ax; beta = c.dt; break;
+            case V_CD: n = XC + 3 * ci + ax; beta = c.dt; break;
+            case V_CDD: n = XCD + 3 * ci + ax; beta = c.dt; break;
+            case V_F: n = XRD + ax; beta = c.dt * c.inv_ms; break;
+            default: break;
+        }
+    }
+
     // element (i,j) of the Gauss-Newton Hessian of L_k (k<N) or L_N (k==N)
     __device__ __forceinline__ static double H_entry(const DevConsts& c, const double* rec, const double* p, int k, int N,
                                                      int i, int j) {
@@ -943,7 +968,9 @@ struct SrbdModel {
     __device__ __forceinline__ static void expand_var(const DevConsts& c, const double* rec, double* FT, int NIP, int lane) {
         expand_var(c, rec, FT, NIP, lane, 64);
     }
-    // WT != nullptr: also writes lam[m] * entry into the extra-row part of (V~ F~)^T (one-wave kernel)
+    // WT != nullptr: also writes lam[m] * entry into the extra-row part of (V~ F~)^T (one-wave kernel).
+    // COMPACT (4-wave kernel): FT is the compact tile [z][dense rows | extra rows] (dense_col), NIP its row stride
+    template <bool COMPACT = false>
     __device__ __forceinline__ static void expand_var(const DevConsts& c, const double* rec, double* FT, int NIP, int tid, int nthreads,
                                                       double* WT = nullptr, const double* lam = nullptr) {
         // two entries per thread and trip, both record reads (and weights) requested before the first store: the single-wave
@@ -981,10 +1008,11 @@ struct SrbdModel {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 if (q == 1 && !two) break;
-                FT[col[q] * NIP + row[q]] = (row[q] == col[q] ? 1.0 : 0.0) + c.dt * raw[q];
+                const int r1 = COMPACT ? dense_col(row[q]) : row[q], r2 = COMPACT ? dense_col(row2[q] >= 0 ? row2[q] : NX) : row2[q];
+                FT[col[q] * NIP + r1] = (row[q] == col[q] ? 1.0 : 0.0) + c.dt * raw[q];
                 if (row2[q] >= 0) {
-                    FT[col[q] * NIP + row2[q]] = raw[q];
-                    if (WT) WT[col[q] * NIP + row2[q]] = lm[q] * raw[q];
+                    FT[col[q] * NIP + r2] = raw[q];
+                    if (WT) WT[col[q] * NIP + r2] = lm[q] * raw[q];
                 }
             }
         }
@@ -1437,8 +1465,27 @@ struct LipModel {
         return kind == 3 ? stage * 2 * c.w_pen * sw * sw : 0.0;
     }
     __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int) {}
+    template <bool COMPACT = false>
     __device__ __forceinline__ static void expand_var(const DevConsts&, const double*, double*, int, int, int, double* = nullptr,
                                                       const double* = nullptr) {}
+    // sparsity of [fx fu] by column (see SrbdModel): no dense rows, every column has the identity and at most one other entry
+    static constexpr int ND = 0;
+    __device__ __forceinline__ static constexpr int dense_row(int) { return 0; }
+    __device__ __forceinline__ static constexpr int dense_col(int row) { return row >= NX ? row - NX : -1; }
+    __device__ static void nbr(const DevConsts& c, int z, int& n, double& beta, double& idc) {
+        int cls, ci, ax;
+        decode(z, cls, ci, ax);
+        idc = z < NX ? 1.0 : 0.0;
+        n = 0; beta = 0.0;
+        switch (cls) {
+            case V_R: n = XRD + ax; beta = c.dt * c.eta2; break;              // F_entry: rdot row, r column
+            case V_RD: n = XR + ax; beta = c.dt; break;
+            case V_CD: n = XC + 3 * ci + ax; beta = c.dt; break;
+            case V_Z: n = XRD + ax; beta = -c.dt * c.eta2; break;
+            case V_CDD: n = XCD + 3 * ci + ax; beta = c.dt; break;
+            default: break;
+        }
+    }
     template <class QM>
     __device__ __forceinline__ static void add_second_order(const DevConsts&, const double*, const double*, QM, double, int, int,
                                                             const double* = nullptr, const int* = nullptr) {}
