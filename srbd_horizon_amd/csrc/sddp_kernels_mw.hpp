@@ -314,12 +314,28 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         if (wave != kLast) {
             M::template expand_var<true>(c, s + L::REC, s + L::FC, SC, tid, kThreadsMW - kWave);
         } else if (lane < NX) {
-            double acc = 0.0;
-#pragma unroll 2
-            for (int m = 0; m < SV; m += 2) {
-                const double2_t v = lds2(s + L::VXX + lane * SV + m), d = lds2(s + L::DK + m);
-                acc = fma(v.y, d.y, fma(v.x, d.x, acc));                                  // pads of DK and Vxx are zero
+            // one row of Vxx against d per lane: four independent partial sums (the FMA chain is the latency of this phase),
+            // operands in groups of four pairs, the next group in flight behind the FMAs of this one
+            constexpr int NP2 = SV / 2, G = 4, NG = (NP2 + G - 1) / G;
+            double a4[4] = {0.0, 0.0, 0.0, 0.0};
+            double2_t vv[2][G], dd[2][G];
+            auto load_g = [&](int g, int buf) {
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+                    if (g * G + q < NP2) { vv[buf][q] = lds2(s + L::VXX + lane * SV + 2 * (g * G + q)); dd[buf][q] = lds2(s + L::DK + 2 * (g * G + q)); }
+            };
+            load_g(0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) load_g(g + 1, (g + 1) & 1);
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+                    if (g * G + q < NP2) {
+                        asm volatile("" : "+v"(vv[g & 1][q]), "+v"(dd[g & 1][q]));
+                        a4[q] = fma(vv[g & 1][q].y, dd[g & 1][q].y, fma(vv[g & 1][q].x, dd[g & 1][q].x, a4[q]));   // pads of DK and Vxx are zero
+                    }
             }
+            const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
             const double d = s[L::DK + lane], vx = s[L::VX + lane];
             s[L::VP + lane] = vx + acc;
             g1_acc += d * vx;
