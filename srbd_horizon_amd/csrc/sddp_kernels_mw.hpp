@@ -90,8 +90,8 @@ struct LdsMW {
     static constexpr int WC = imax(WT + RZ * SV, GT + 2 * RPW * kWave);      // (small models: the tile is sized by what it hosts)
     static constexpr int QU = WC + RZ * SC;             // [NU][SQ]: row i = row NX + i of Q (columns: state | input)
     static constexpr int SWEEP_END = QU + NU * SQ;
-    // forward pass: per-lane vector columns X | Y | U and the staged gains of one knot
-    static constexpr int RO_X = WORK, RO_Y = RO_X + NX * kWave, RO_U = RO_Y + NX * kWave, RO_G = RO_U + NU * kWave;
+    // forward pass: per-lane vector columns X | U and the staged gains of one knot
+    static constexpr int RO_X = WORK, RO_U = RO_X + NX * kWave, RO_G = RO_U + NU * kWave;
     static constexpr int RO_K = RO_G + ((NU + 1) & ~1);                        // kff [NU] | K [NU][SG]
     // knot operands staged beside the gains, double buffered: x_k [SG] | u_k [NUE] | d_k [SG] | p_k [NPE]
     static constexpr int NUE = (NU + 1) & ~1, NPE = (M::NP + 1) & ~1;
@@ -641,7 +641,7 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
     constexpr int kStagers = kThreadsMW - kWave;
     constexpr int NSB = 2 * NX + NU + NP;
     const int lane = tid & (kWave - 1), wave = tid / kWave;
-    const LdsCol X{s + L::RO_X + lane}, Y{s + L::RO_Y + lane}, U{s + L::RO_U + lane};
+    const LdsCol X{s + L::RO_X + lane}, U{s + L::RO_U + lane};
     double* kf = s + L::RO_G;                                      // staged gains of one knot: kff [NU]
     double* kb = s + L::RO_K;                                      //                           K [NU][SG]
     auto stage_knot = [&](int k) {                                 // waves 1..3
@@ -663,7 +663,7 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
     };
     __syncthreads();                                               // the tiles this pass aliases are no longer read
     if (wave == 0) {
-        for (int i = 0; i < NX; ++i) Y[i] = x0[i];
+        for (int i = 0; i < NX; ++i) X[i] = x0[i];
     } else {
         stage_knot(0);
     }
@@ -672,24 +672,7 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
     for (int k = 0; k < N; ++k) {
         SDDP_TICK(8)
         const double* sb = s + L::RO_S + (k & 1) * L::SB_N;
-        // ---- A: wave 0 closes the previous knot: x_k = f(x_{k-1}, u_{k-1}) - (1 - alpha) d_{k-1}
-        if (wave == 0) {   // all loads before the first store: the compiler cannot tell the X and Y columns apart
-            double t[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) t[i] = Y[i];
-            if (!(k == 0 || OPEN_LOOP)) {
-                const double* dprev = s + L::RO_S + ((k - 1) & 1) * L::SB_N + L::SB_D;
-                double dv[NX];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) dv[i] = dprev[i];
-                pin_regs(t);                     // every read in flight before the first use (see pin_regs)
-                pin_regs(dv);
-#pragma unroll
-                for (int i = 0; i < NX; ++i) t[i] -= oma * dv[i];
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) X[i] = t[i];
-        }
+        // (x_k is in the X columns: x0, or written by the step of knot k - 1, which also closed that knot -- LdsColClose)
         __syncthreads();
         SDDP_TICK(11)
         // ---- B: every wave computes UPW rows of u = u_k + alpha kff + K (x - x_k)
@@ -766,7 +749,9 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
         SDDP_TICK(10)
         // ---- C: wave 0 steps the model; the other waves write the stored lane's u_k and stage the next knot
         if (wave == 0) {
-            J += M::step(c, X, U, sb + L::SB_P, k, Y);
+            // x_{k+1} = f(x_k, u_k) - (1 - alpha) d_k straight into the X columns (the step forms x+ before its first store)
+            if (OPEN_LOOP) J += M::step(c, X, U, sb + L::SB_P, k, X);
+            else J += M::step(c, X, U, sb + L::SB_P, k, LdsColClose{X.p, sb + L::SB_D, oma});
         } else {
             if (tid - kWave < NU) un[k * NU + tid - kWave] = s[L::RO_U + (tid - kWave) * kWave + store_lane];
             if (k + 1 < N) stage_knot(k + 1);
@@ -774,17 +759,6 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
         SDDP_TICK(12)
     }
     if (wave == 0) {
-        if (OPEN_LOOP) { for (int i = 0; i < NX; ++i) X[i] = Y[i]; }
-        else {
-            const double* dprev = s + L::RO_S + ((N - 1) & 1) * L::SB_N + L::SB_D;
-            double t[NX], dv[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) { t[i] = Y[i]; dv[i] = dprev[i]; }
-            pin_regs(t);
-            pin_regs(dv);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) X[i] = t[i] - oma * dv[i];
-        }
         J += M::term_cost(c, X, P + N * NP);
         if (lane == store_lane) {
             for (int i = 0; i < NX; ++i) xn[N * NX + i] = X[i];

@@ -81,6 +81,17 @@ struct LdsCol {
     __device__ __forceinline__ LdsCol operator+(int off) const { return LdsCol{p + off * 64}; }
 };
 
+// Store-only view of such a column that closes a knot of the multiple-shooting rollout while the model step writes its result:
+// element i receives v - oma * d[i]  (x_{k+1} = f(x_k, u_k) - (1 - alpha) d_k; d: the knot's staged defect, broadcast reads)
+struct LdsColClose {
+    double* p; const double* d; double oma;
+    struct Ref {
+        double* q; double di, oma;
+        __device__ __forceinline__ void operator=(double v) const { *q = fma(-oma, di, v); }
+    };
+    __device__ __forceinline__ Ref operator[](int i) const { return Ref{p + i * 64, d[i], oma}; }
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // small fixed-size helpers (all indices compile-time after unrolling -> registers)
 // ---------------------------------------------------------------------------------------------------------
