@@ -145,6 +145,18 @@ def test_throughput_build_returns_the_same_results_as_the_latency_build():
     np.testing.assert_allclose(rs[1][0], rs[0][0], rtol=0, atol=1e-9)
     np.testing.assert_allclose(rs[1][1], rs[0][1], rtol=0, atol=1e-9)
     assert rs[1][3][1] == 2 * rs[0][3][1] == 512 and rs[0][3][2] == rs[1][3][2] == 600, (rs[0][3], rs[1][3])
+    # the full second-order build of srbd37 (its own kernel instantiation, larger tables) in both register budgets
+    b2 = workload.make_batch("srbd37", 20, np.arange(24))
+    r2 = []
+    for w in (1, 2):
+        eng = DdpEngine("srbd37", 20, 24, opts=dict(opts, waves_per_simd=w, second_order=2))
+        eng.set_initial_state(b2["x0"]); eng.set_x_warmstart(b2["xs"]); eng.set_u_warmstart(b2["us"])
+        x, u = eng.solve(b2["params"])
+        r2.append((x, u, eng.stats.copy()))
+    np.testing.assert_array_equal(r2[0][2]["iters"], r2[1][2]["iters"])
+    np.testing.assert_allclose(r2[1][0], r2[0][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(r2[1][1], r2[0][1], rtol=0, atol=1e-9)
+    assert np.all(r2[0][2]["converged"] == 1)
 
 
 def test_batches_in_flight_on_separate_streams_equal_sequential_solves():
