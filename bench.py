@@ -342,6 +342,7 @@ def main():
         out.update(single_instance_extras(N, opts, workload, DdpEngine))
         out["ms_per_fleet_tick"] = fleet_tick(N, B, opts, workload, DdpEngine)
         out["tick_ms_vs_batch"] = tick_curve(N, opts, workload, DdpEngine)
+        out["ms_per_fleet_tick_srbd37"] = fleet_tick_reference_model(opts, workload, DdpEngine)
         # PCIe-inclusive batch rate (host-pointer C-ABI call: params in, x/u/stats out) -- reported, never `value`
         e_h = DdpEngine("srbd13", N, B, opts=dict(opts, waves_per_simd=1))
         e_h.set_initial_state(batch["x0"])
@@ -483,6 +484,55 @@ def fleet_tick(N, B, opts, workload, DdpEngine, ticks=100, budget=6, cpu_ticks=6
                     "sddp_solve_resident incl. the PCIe copies of p_last / x0 in and x / u / stats out; CPU = the C port, OpenMP over robots; "
                     "a tick to convergence ends with its slowest robot (slowest_ticks: its iteration count), the budgeted run caps "
                     "every robot at max_iters_per_tick and carries unfinished iterates over"}
+
+
+def fleet_tick_reference_model(opts, workload, DdpEngine, model="srbd37", N=20, B=512, ticks=28, cpu_ticks=4):
+    """ms / MPC tick of a fleet of the REFERENCE's own robots (srbd37, ns = 20: the problem dsrbd_example.py runs): B robots, one
+    four-wavefront workgroup each, all resident at two workgroups per CU; warm-started ticks as in fleet_tick, only what a tick
+    applies is fetched (sddp_solve_resident_first).  CPU: the C port on the host threads for the last ticks, same problems."""
+    from oracle import cport, ddp as oddp, models as omodels
+    b = workload.make_batch(model, N, np.arange(B) + 11000)
+    cst, o = omodels.RobotConsts(), oddp.DdpOptions(**opts)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    e = DdpEngine(model, N, B, opts=dict(opts, waves_per_simd=2))
+    e.enable_timing(True)
+    e.set_initial_state(b["x0"]); e.set_x_warmstart(b["xs"]); e.set_u_warmstart(b["us"])
+    e.set_params(b["params"])
+    x, u = e.solve_resident()
+    P = b["params"].copy()
+    gms, kms, cms, same, imean, imax = [], [], [], [], [], []
+    for t in range(ticks):
+        p_last, x0 = P[:, -1].copy(), x[:, 1].copy()
+        xs_ws = np.concatenate([x[:, 1:], x[:, -1:]], axis=1); xs_ws[:, 0] = x0
+        us_ws = np.concatenate([u[:, 1:], u[:, -1:]], axis=1)
+        P = np.concatenate([P[:, 1:], p_last[:, None]], axis=1)
+        t1 = time.perf_counter()
+        e.advance(p_last, x0)
+        e.solve_resident_first()
+        gms.append(1e3 * (time.perf_counter() - t1))
+        kms.append(e.last_kernel_ms())
+        x, u, st = e.fetch()                                   # outside the timed tick: the CPU replay needs the whole warm start
+        it = st["iters"]
+        imean.append(float(it.mean())); imax.append(int(it.max()))
+        if t >= ticks - cpu_ticks:
+            t1 = time.perf_counter()
+            _, _, cs = cport.solve_batch(cst, o, x0, P, xs_ws, us_ws, threads=threads, model=model)
+            cms.append(1e3 * (time.perf_counter() - t1))
+            same.append(float(np.mean(cs[:, 1].astype(int) == it)))
+    g = np.array(gms[4:ticks - cpu_ticks])                     # the ticks before the host threads were handed to the CPU replay
+    slots, grid, queued = e.queue_info()
+    return {"model": model, "horizon_N": N, "batch": B, "ticks": len(g), "slots": slots,
+            "gpu_ms_per_tick_median": float(np.median(g)), "gpu_ms_per_tick_p99": float(np.percentile(g, 99)), "gpu_ms_per_tick_max": float(g.max()),
+            "mean_iters": float(np.mean(imean[4:])), "iters_max_per_tick_median": float(np.median(imax[4:])), "iters_max": int(np.max(imax[4:])),
+            "gpu_kernel_ms_per_tick_median": float(np.median(kms[4:ticks - cpu_ticks])), "gpu_kernel_ms_per_tick_max": float(np.max(kms[4:ticks - cpu_ticks])),
+            "cpu_ms_per_tick_median": float(np.median(cms[1:])), "cpu_ms_per_tick_all": [float(v) for v in cms], "cpu_threads": threads,
+            "same_iters_as_gpu_frac": float(np.mean(same)),
+            "note": f"{model} N={N}: {B} robots of the reference's own problem, warm-started ticks, sddp_advance + sddp_solve_resident_first "
+                    "(first input, next state, cost, iterations, status of every robot over PCIe), two workgroups per CU; CPU = the C port, "
+                    "OpenMP over robots, the same ticks (the first of its ticks warms the threads' work arrays up and is left out of the median).  "
+                    "gpu_kernel_ms_*: the solve kernel alone by HIP events -- one tick per process shows a host-side stall of 20-45 ms inside the "
+                    "launch / wait (the HIP runtime growing a submission pool at a fixed launch count) while its kernel takes as long as every other: "
+                    "that is the p99 / max of this short run"}
 
 
 def tick_curve(N, opts, workload, DdpEngine, batches=(1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024), ticks=24, cpu_ticks=3):
