@@ -57,7 +57,7 @@ typedef struct sddp_options {
                                            half the register file, two instances resident per SIMD (srbd13) or two workgroups
                                            per CU (the 4-wavefront kernel of srbd37 / lip30, whose tiles fit a CU's LDS twice)
                                            -- highest solves/s for queues of many instances.  A build
-                                           whose tiles do not fit twice (srbd37 with barrier + second_order 2) runs as with 1. */
+                                           that gains no resident workgroup from it (srbd37 with a barrier) runs as with 1. */
     int    queue_order;                 /* scheduling hint, no effect on results.  A solve launch runs on the workgroups that are
                                            resident on the device at once ("slots": 256 CUs x 4 SIMDs x waves_per_simd for srbd13,
                                            256 CUs x waves_per_simd for srbd37 / lip30);

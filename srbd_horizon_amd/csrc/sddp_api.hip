@@ -182,6 +182,15 @@ int launch_solve(sddp_handle* h, SolveArgs a, int first, int count) {
     int slots = 0;
     int rc = kernel_slots<M>(h, kern, &slots);
     if (rc != SDDP_OK) return rc;
+    if constexpr (MW) {   // a half-register-file build that the device still runs one per CU (barrier builds) has nothing to offer
+        if (h->opts.waves_per_simd >= 2) {
+            KernelFn k1 = pick_solve<M>(1);
+            int s1 = 0;
+            rc = kernel_slots<M>(h, k1, &s1);
+            if (rc != SDDP_OK) return rc;
+            if (s1 >= slots) { kern = k1; slots = s1; }
+        }
+    }
     int grid = std::min(count, std::min(slots, h->wslots));
     if (h->opts.max_slots > 0) grid = std::min(grid, h->opts.max_slots);
     a.first = first; a.count = count;
