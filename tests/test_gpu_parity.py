@@ -161,13 +161,15 @@ def test_iteration_by_iteration_trace_matches_oracle():
         eng.close()
 
 
-def test_regularisation_bump_on_indefinite_quu():
-    """mu0 < 0 large makes Quu indefinite: the engine must bump mu (ddp.py:34-35) exactly like the oracle."""
-    N, seeds = 30, [3]
-    batch = workload.make_batch("srbd13", N, seeds)
-    m = _oracle_model("srbd13")
+@pytest.mark.parametrize("model,N", [("srbd13", 30), ("srbd37", 20), ("lip30", 20)])
+def test_regularisation_bump_on_indefinite_quu(model, N):
+    """mu0 < 0 large makes Quu indefinite: the engine must bump mu (ddp.py:34-35) exactly like the oracle.  On the 4-wavefront
+    kernel (srbd37, lip30) a failed sweep leaves tiles that alias each other half-written: the retry must not see them."""
+    seeds = [3]
+    batch = workload.make_batch(model, N, seeds)
+    m = _oracle_model(model)
     over = dict(mu0=-1e9, max_iters=3)
-    eng = DdpEngine("srbd13", N, 1, opts=_opts(**over))
+    eng = DdpEngine(model, N, 1, opts=_opts(**over))
     eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
     x, u = eng.solve(batch["params"])
     r = oddp.solve(m, batch["x0"][0], batch["params"][0], batch["xs"][0], batch["us"][0], _oracle_opts(**over))
