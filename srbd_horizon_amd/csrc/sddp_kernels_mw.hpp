@@ -189,7 +189,7 @@ __device__ void ft_constants_mw(const DevConsts& c, double* s, int t, int nthrea
 template <class M>
 __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
     using L = LdsMW<M>;
-    constexpr int NX = M::NX, NZ = M::NZ, NE = M::NE, NEV = M::NEV;
+    constexpr int NZ = M::NZ, NE = M::NE;
     for (int e = tid; e < L::WORK; e += kThreadsMW) s[e] = 0.0;
     zero_work_mw<M>(s, tid, kThreadsMW);
     __syncthreads();
@@ -212,11 +212,10 @@ __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
 }
 
 // The constant extra rows (m >= NEV: node-independent weights) contribute sum_m lambda_m E[m][row] E[m][col] to Q: a constant
-// matrix.  Each thread keeps the 3x3 block it owns in the Q phase in registers for the whole kernel (call after sweep_tables_mw).
+// matrix.  Each thread keeps the 3x3 block it owns in the Q phase in registers for the whole kernel.
 template <class M>
-__device__ void mw_const_block(const DevConsts& c, const double* s, int tid, double (&qconst)[3][3]) {
+__device__ void mw_const_block(const DevConsts& c, int tid, double (&qconst)[3][3]) {
     using L = LdsMW<M>;
-    const int* ki = reinterpret_cast<const int*>(s + L::KI);
     const int code = tid < L::NTRIQ ? tri_code(tid) : 0;
     const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
 #pragma unroll
@@ -789,7 +788,7 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
     SDDP_T_DECL
     sweep_tables_mw<M>(A.c, s, tid);
     double qconst[3][3];
-    mw_const_block<M>(A.c, s, tid, qconst);
+    mw_const_block<M>(A.c, tid, qconst);
     // ---- starting point (cost and defect norm computed by wave 0, shared through CTL)
     if (o.initial_rollout) {
         J = rollout_mw<M, true>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, tid, s SDDP_T_PASS);
@@ -1002,7 +1001,7 @@ __global__ __launch_bounds__(kThreadsMW) void backward_kernel_mw(SolveArgs A) {
     __syncthreads();
     double dV1, G1, G2, qu_inf;
     double qconst[3][3];
-    mw_const_block<M>(A.c, s, tid, qconst);
+    mw_const_block<M>(A.c, tid, qconst);
     const bool ok = backward_sweep_mw<M>(A.c, N, P, dft, rec, gains, A.mu, A.alpha, s, tid, dV1, G1, G2, qu_inf, qconst SDDP_T_PASS);
     if (tid == 0) {
         double* sc = A.scal + size_t(b) * kScal;
