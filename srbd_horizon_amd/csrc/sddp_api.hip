@@ -98,6 +98,16 @@ struct sddp_handle {
 
 namespace {
 
+// host scratch of a call: plain malloc (no exception can cross the C boundary), freed on every return path
+struct host_buf {
+    void* p;
+    explicit host_buf(size_t bytes) : p(std::malloc(bytes ? bytes : 1)) {}
+    ~host_buf() { std::free(p); }
+    host_buf(const host_buf&) = delete;
+    host_buf& operator=(const host_buf&) = delete;
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 int fail(sddp_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_create_error = msg;
     return code;
@@ -223,7 +233,7 @@ int launch_solve(sddp_handle* h, SolveArgs a, int first, int count) {
         while (h->ev.size() < 2 * (h->pending + 1)) {
             hipEvent_t e;
             HIP_TRY(h, hipEventCreate(&e));
-            h->ev.push_back(e);
+            try { h->ev.push_back(e); } catch (...) { (void)hipEventDestroy(e); return fail(h, SDDP_ERR_NOMEM, "out of host memory"); }
         }
         e0 = h->ev[2 * h->pending];
         e1 = h->ev[2 * h->pending + 1];
@@ -747,9 +757,9 @@ int sddp_solve_resident_first(sddp_handle* h, double* u0_out, double* x1_out, do
     const int grid = int(std::min<size_t>((size_t(h->B) * w + 255) / 256, 1024));
     hipLaunchKernelGGL(first_knot_kernel, dim3(grid), dim3(256), 0, h->stream, h->N, h->B, h->d.nx, h->d.nu, h->xs, h->us, h->stats, h->first_dev);
     HIP_TRY(h, hipGetLastError());
-    std::vector<double> tmp;
-    double* host = h->first_pin;
-    if (!host) { tmp.resize(size_t(h->B) * w); host = tmp.data(); }
+    host_buf tmp(h->first_pin ? 0 : bytes);
+    if (!tmp.p) return fail(h, SDDP_ERR_NOMEM, "out of host memory");
+    double* host = h->first_pin ? h->first_pin : tmp.as<double>();
     HIP_TRY(h, hipMemcpyAsync(host, h->first_dev, bytes, hipMemcpyDeviceToHost, h->stream));
     rc = sddp_synchronize(h);
     if (rc != SDDP_OK) return rc;
@@ -801,8 +811,10 @@ int sddp_model_step(sddp_handle* h, const double* x, const double* u, const doub
 
 int sddp_is_converged(sddp_handle* h, int* flags) {
     if (!h || !flags) return SDDP_ERR_ARG;
-    std::vector<sddp_stats> st(h->B);
-    HIP_TRY(h, hipMemcpyAsync(st.data(), h->stats, size_t(h->B) * sizeof(sddp_stats), hipMemcpyDeviceToHost, h->stream));
+    host_buf buf(size_t(h->B) * sizeof(sddp_stats));
+    if (!buf.p) return fail(h, SDDP_ERR_NOMEM, "out of host memory");
+    sddp_stats* st = buf.as<sddp_stats>();
+    HIP_TRY(h, hipMemcpyAsync(st, h->stats, size_t(h->B) * sizeof(sddp_stats), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (int b = 0; b < h->B; ++b) flags[b] = st[b].converged;
     return SDDP_OK;
@@ -926,8 +938,10 @@ int sddp_backward(sddp_handle* h, const double* params, double mu, double* gains
     if (gains_out) HIP_TRY(h, hipMemcpyAsync(gains_out, h->gains, h->n_g() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (scal_out) {
-        std::vector<double> sc(size_t(h->B) * kScal);
-        HIP_TRY(h, hipMemcpy(sc.data(), h->scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost));
+        host_buf buf(size_t(h->B) * kScal * sizeof(double));
+        if (!buf.p) return fail(h, SDDP_ERR_NOMEM, "out of host memory");
+        const double* sc = buf.as<double>();
+        HIP_TRY(h, hipMemcpy(buf.p, h->scal, size_t(h->B) * kScal * sizeof(double), hipMemcpyDeviceToHost));
         for (int b = 0; b < h->B; ++b)
             for (int i = 0; i < 8; ++i) scal_out[size_t(b) * 8 + i] = sc[size_t(b) * kScal + i];
     }
@@ -948,8 +962,10 @@ int sddp_forward(sddp_handle* h, const double* params, double alpha, double* x_o
     if (u_out) HIP_TRY(h, hipMemcpyAsync(u_out, h->un, h->n_u() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (cost_out) {
-        std::vector<double> sc(size_t(h->B) * kScal);
-        HIP_TRY(h, hipMemcpy(sc.data(), h->scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost));
+        host_buf buf(size_t(h->B) * kScal * sizeof(double));
+        if (!buf.p) return fail(h, SDDP_ERR_NOMEM, "out of host memory");
+        const double* sc = buf.as<double>();
+        HIP_TRY(h, hipMemcpy(buf.p, h->scal, size_t(h->B) * kScal * sizeof(double), hipMemcpyDeviceToHost));
         for (int b = 0; b < h->B; ++b) cost_out[b] = sc[size_t(b) * kScal];
     }
     return SDDP_OK;
