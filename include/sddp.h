@@ -20,12 +20,14 @@
 extern "C" {
 #endif
 
-#define SDDP_ABI_VERSION 7
+#define SDDP_ABI_VERSION 8
 
 /* model ids */
 #define SDDP_MODEL_SRBD13 0 /* nx=13 nu=6  np=19 : BASELINE.json metric model (contacts are per-knot parameters) */
 #define SDDP_MODEL_SRBD37 1 /* nx=37 nu=24 np=19 : reference SRBD problem, prb.py:16-246                        */
 #define SDDP_MODEL_LIP30  2 /* nx=30 nu=15 np=11 : reference LIP problem,  prb.py:248-441                       */
+#define SDDP_MODEL_SRBD61 3 /* nx=61 nu=48 np=27 : reference SRBD problem at its code-default contact_model = 4
+                               (nc = 8, prb.py:39-41); default build only (no barrier, no second_order = 2)        */
 
 /* status codes */
 #define SDDP_OK 0
@@ -80,7 +82,8 @@ typedef struct sddp_model_consts {
     double m;              /* kg                                   prb.py:92    */
     double I[9];           /* kg m^2, row major                    prb.py:94-95 */
     double com[3];         /*                                      prb.py:138   */
-    double feet[12];       /* 4 contact points x 3, row major      prb.py:130-131 */
+    double feet[12];       /* contact points 0..3 x 3, row major   prb.py:130-131 (all the graphs use: d_initial_1/2 of
+                              prb.py:153-154 index feet 0..3 whatever nc is; the other feet only enter x0 / c_ref, host side) */
     double dt;             /* T/ns                                 prb.py:110   */
     double force_scaling;  /* 1000                                 prb.py:98    */
     double r_tracking_gain, rdot_tracking_gain, w_tracking_gain, rel_pos_gain;       /* prb.py:142-147 */
@@ -165,6 +168,10 @@ int  sddp_load_range_device(sddp_handle* h, int first, int count, const double* 
 int  sddp_solve_range_device(sddp_handle* h, const double* d_params, int first, int count);
 /* slots: resident workgroups the work buffers exist for; grid and queue length (0: no queue) of the last solve launch */
 int  sddp_queue_info(sddp_handle* h, int* slots, int* last_grid, int* last_queued);
+/* which kernel a handle runs: wavefronts per instance (1: solve_kernel, 4: solve_kernel_mw), the build the LAST solve launch used
+ * (1: full register file, 2: the `_w2` half-register-file build -- a handle asked for 2 falls back to 1 where that gains no
+ * resident workgroup) and the model name the kernels are instantiated for.  Any pointer may be NULL. */
+int  sddp_kernel_info(sddp_handle* h, int* wavefronts_per_instance, int* last_waves_per_simd, const char** model_name);
 /* results of the last device solve (x, u, stats of the whole batch) to host pointers; waits for the stream */
 int  sddp_fetch(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats /*[B] or NULL*/);
 /* which: 0 xs [B][N+1][nx], 1 us [B][N][nu], 2 stats [B] (sddp_stats), 3 gains [slots][N][nu*(nx+1)], 4 x0 [B][nx],

@@ -1,4 +1,4 @@
-/* TEST INFRASTRUCTURE ONLY -- plain C restatement of the three problems (srbd13, srbd37, lip30) and, through ddp_engine.inc, of
+/* TEST INFRASTRUCTURE ONLY -- plain C restatement of the four problems (srbd13, srbd37, srbd61, lip30) and, through ddp_engine.inc, of
  * the MS-DDP iteration (same steps, same order as oracle/models.py + oracle/ddp.py, which carry the reference file:line
  * citations).
  * PARITY UNPINNED upstream (the reference engine `pyddp` is absent): this file is pinned against the numpy oracle in
@@ -104,7 +104,7 @@ static int chol(double* A, int n) {
 
 /* ---- SRBD accelerations for nc contacts (Horizon kin_dyn.fSRBD, prb.py:99; oracle/models.py srbd_acc / srbd_acc_jac) ---- */
 typedef struct { double R[9], M[9], Mi[9], wdot[3], rddot[3]; } core_t;
-typedef struct { double Wr[9], Wo[12], Ww[9], Wc[4][9], Wf[4][9]; } corejac_t;   /* d wdot / d r, o, w, c_i, f_i */
+typedef struct { double Wr[9], Wo[12], Ww[9], Wc[8][9], Wf[8][9]; } corejac_t;   /* d wdot / d r, o, w, c_i, f_i */
 
 static void core_n(const consts_t* c, const double* r, const double* o, const double* w, int nc, const double* const* cs,
                    const double* const* fs, core_t* k) {
@@ -170,7 +170,7 @@ static void wdot_hess_contract(const consts_t* c, const double* r, const double*
     const int n = 10 + 6 * nc;
     core_t k; corejac_t J;
     core_n(c, r, o, w, nc, cs, fs, &k); corejac_n(c, r, o, w, nc, cs, fs, &k, &J);
-    double Jw[3][34];                                   /* d wdot / d z in the local order */
+    double Jw[3][58];                                   /* d wdot / d z in the local order */
     for (int a = 0; a < 3; ++a) {
         for (int b = 0; b < 3; ++b) { Jw[a][b] = J.Wr[3 * a + b]; Jw[a][7 + b] = J.Ww[3 * a + b]; }
         for (int b = 0; b < 4; ++b) Jw[a][3 + b] = J.Wo[4 * a + b];
@@ -221,7 +221,7 @@ static void srbd_second_order_full(const consts_t* c, const double* r, const dou
                                    double theta, double* Q, int nz) {
     const int n = 10 + 6 * nc;
     core_t k; core_n(c, r, o, w, nc, cs, fs, &k);
-    double lam[3], S[34 * 34];
+    double lam[3], S[58 * 58];
     for (int m = 0; m < 3; ++m) lam[m] = c->dt * vp_w[m] + 2.0 * c->gq * k.wdot[m];
     memset(S, 0, sizeof(double) * n * n);
     wdot_hess_contract(c, r, o, w, nc, cs, fs, lam, S);
@@ -347,19 +347,23 @@ static int rel_pos_rows(const consts_t* c, const double* x, const int* C0, doubl
     }
     return n;
 }
-/* equality constraints as sqrt(1e6)-weighted residuals (ddp.py:195-196; prb.py:166-170, :179-181), contact_model = 2: 16 rows */
-static int contact_penalty_rows(const double* x, const int* C0, const int* CD0, const double* cref, const double* sw, double* r, double* J,
-                                int nz, int n) {
+/* equality constraints as sqrt(1e6)-weighted residuals (ddp.py:195-196; prb.py:166-170, :179-181) for nc contacts, contact_model
+ * cm = nc / 2 per foot: relative_vel_left_i (cdot_0 - cdot_i, i = 1..cm-1), relative_vel_right_i (cdot_cm - cdot_i, i = cm+1..2cm-1),
+ * then per contact cz_tracking_i and cdotxy_tracking_i: 4 (cm - 1) + 3 nc rows */
+static int contact_penalty_rows(const double* x, int nc, const int* C0, const int* CD0, const double* cref, const double* sw, double* r,
+                                double* J, int nz, int n) {
     const double g = sqrt(CW);
-    const int lead[2] = {0, 2}, foll[2] = {1, 3};
-    for (int t = 0; t < 2; ++t) {                                       /* relative_vel_left_1, relative_vel_right_3 */
-        for (int e = 0; e < 2; ++e) {
-            r[n + e] = g * (x[CD0[lead[t]] + e] - x[CD0[foll[t]] + e]);
-            if (J) { J[(n + e) * nz + CD0[lead[t]] + e] = g; J[(n + e) * nz + CD0[foll[t]] + e] = -g; }
+    const int cm = nc / 2;
+    for (int leg = 0; leg < 2; ++leg)
+        for (int i = 1; i < cm; ++i) {
+            const int lead = leg * cm, foll = leg * cm + i;
+            for (int e = 0; e < 2; ++e) {
+                r[n + e] = g * (x[CD0[lead] + e] - x[CD0[foll] + e]);
+                if (J) { J[(n + e) * nz + CD0[lead] + e] = g; J[(n + e) * nz + CD0[foll] + e] = -g; }
+            }
+            n += 2;
         }
-        n += 2;
-    }
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < nc; ++i) {
         r[n] = g * (x[C0[i] + 2] - cref[i]); if (J) J[n * nz + C0[i] + 2] = g; ++n;                 /* cz_tracking_i */
         for (int e = 0; e < 2; ++e) { r[n + e] = g * sw[i] * x[CD0[i] + e]; if (J) J[(n + e) * nz + CD0[i] + e] = g * sw[i]; }
         n += 2;                                                                                      /* cdotxy_tracking_i */
@@ -470,133 +474,21 @@ static void s13_second_order(const consts_t* c, const double* x, const double* u
 #undef NR
 #undef MDL
 
-/* =================================================== srbd37 ===========================================================
- * x = r | o | c0..c3 | rdot | w | cdot0..3 ; u = (cddot_i, f_i) x 4 interleaved (prb.py:32-68) ;
- * p = rdot_ref | w_ref | otg | (c_ref_i, sw_i) x 4 | oref   */
-#define NX 37
-#define NU 24
-#define NP 19
+/* ============================================== srbd37 and srbd61 ======================================================
+ * the reference problem with the contacts as states (srbd_cs.inc): nc = 4 (launch file, contact_model = 2) and nc = 8 (the
+ * code default contact_model = 4, prb.py:39-41) */
+#define NCC 4
 #define NR 218 /* 15 state + 18 min_qddot + 24 force (+ 20 barrier) + 16 penalty rows (+ 2 x 61 bound rows) */
 #define MDL(n) s37_##n
-static const int S37_C[4] = {7, 10, 13, 16}, S37_CD[4] = {25, 28, 31, 34};
-static void s37_core(const consts_t* c, const double* x, const double* u, core_t* k, corejac_t* J) {
-    const double* cs[4] = {x + 7, x + 10, x + 13, x + 16}; const double* fs[4] = {u + 3, u + 9, u + 15, u + 21};
-    core_n(c, x, x + 3, x + 22, 4, cs, fs, k);
-    if (J) corejac_n(c, x, x + 3, x + 22, 4, cs, fs, k, J);
-}
-static void s37_dyn_k(const consts_t* c, const double* x, const double* u, const core_t* kp, double* xn) {
-    const core_t k = *kp;
-    const double dt = c->dt;
-    double on[4], tmp[37]; quat_step(x + 3, x + 22, dt, on);
-    for (int a = 0; a < 3; ++a) {
-        tmp[a] = x[a] + dt * x[19 + a];
-        tmp[19 + a] = x[19 + a] + dt * k.rddot[a];
-        tmp[22 + a] = x[22 + a] + dt * k.wdot[a];
-    }
-    for (int a = 0; a < 4; ++a) tmp[3 + a] = on[a];
-    for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) {
-        tmp[7 + 3 * i + a] = x[7 + 3 * i + a] + dt * x[25 + 3 * i + a];
-        tmp[25 + 3 * i + a] = x[25 + 3 * i + a] + dt * u[6 * i + a];
-    }
-    memcpy(xn, tmp, sizeof(tmp));
-}
-static void s37_dyn(const consts_t* c, const double* x, const double* u, const double* p, double* xn) {
-    (void)p;
-    core_t k; s37_core(c, x, u, &k, NULL);
-    s37_dyn_k(c, x, u, &k, xn);
-}
-static void s37_wrows(const corejac_t* Jc, double g, double* M, int nz, int row0) {
-    for (int a = 0; a < 3; ++a) {
-        for (int b = 0; b < 3; ++b) { M[(row0 + a) * nz + b] += g * Jc->Wr[3 * a + b]; M[(row0 + a) * nz + 22 + b] += g * Jc->Ww[3 * a + b]; }
-        for (int b = 0; b < 4; ++b) M[(row0 + a) * nz + 3 + b] += g * Jc->Wo[4 * a + b];
-        for (int i = 0; i < 4; ++i) for (int b = 0; b < 3; ++b) {
-            M[(row0 + a) * nz + 7 + 3 * i + b] += g * Jc->Wc[i][3 * a + b];
-            M[(row0 + a) * nz + 37 + 6 * i + 3 + b] += g * Jc->Wf[i][3 * a + b];
-        }
-    }
-}
-static void s37_dyn_jac(const consts_t* c, const double* x, const double* u, const double* p, double* F /*37x61*/) {
-    (void)p;
-    core_t k; corejac_t Jc; s37_core(c, x, u, &k, &Jc);
-    const double dt = c->dt; const int nz = 61;
-    memset(F, 0, sizeof(double) * 37 * nz);
-    for (int i = 0; i < 37; ++i) F[i * nz + i] = 1.0;
-    for (int a = 0; a < 3; ++a) {
-        F[a * nz + 19 + a] += dt;
-        for (int i = 0; i < 4; ++i) {
-            F[(19 + a) * nz + 37 + 6 * i + 3 + a] = dt * c->inv_ms;
-            F[(7 + 3 * i + a) * nz + 25 + 3 * i + a] += dt;
-            F[(25 + 3 * i + a) * nz + 37 + 6 * i + a] = dt;
-        }
-    }
-    s37_wrows(&Jc, dt, F, nz, 22);
-    quat_jac(x + 3, x + 22, dt, F, nz, 3, 22);
-}
-static int s37_residual_k(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J, const core_t* pre) {
-    int n = 0; const int nz = 61;
-    if (J) memset(J, 0, sizeof(double) * NR * nz);
-    if (!u || k >= 1) {
-        n = srbd_state_rows(c, x, 0, 3, 19, 22, p, p + 3, p[6], p + 15, r, J, nz, n);
-        n = rel_pos_rows(c, x, S37_C, r, J, nz, n);
-    }
-    if (u) {
-        core_t kk; corejac_t Jc;
-        if (pre && !J) kk = *pre; else s37_core(c, x, u, &kk, J ? &Jc : NULL);
-        const double g = sqrt(c->gq);
-        for (int a = 0; a < 3; ++a) { r[n + a] = g * kk.rddot[a]; r[n + 3 + a] = g * kk.wdot[a]; }
-        for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) { r[n + 6 + 3 * i + a] = g * u[6 * i + a]; if (J) J[(n + 6 + 3 * i + a) * nz + 37 + 6 * i + a] = g; }
-        if (J) {
-            for (int a = 0; a < 3; ++a) for (int i = 0; i < 4; ++i) J[(n + a) * nz + 37 + 6 * i + 3 + a] = g * c->inv_ms;
-            s37_wrows(&Jc, g, J, nz, n + 3);
-        }
-        n += 18;
-        double cref[4], sw[4];
-        for (int i = 0; i < 4; ++i) { cref[i] = p[7 + 2 * i]; sw[i] = p[8 + 2 * i]; }
-        for (int i = 0; i < 4; ++i) n = force_rows(c, u + 6 * i + 3, sw[i], 37 + 6 * i + 3, r, J, nz, n);
-        n = contact_penalty_rows(x, S37_C, S37_CD, cref, sw, r, J, nz, n);
-        n = bound_rows(c, x, u, 37, 24, r, J, n);
-    }
-    return n;
-}
-static int s37_residual(const consts_t* c, const double* x, const double* u, const double* p, int k, double* r, double* J) {
-    return s37_residual_k(c, x, u, p, k, r, J, NULL);
-}
-static double s37_stepcost(const consts_t* c, const double* x, const double* u, const double* p, int k, double* xn) {
-    core_t kk; s37_core(c, x, u, &kk, NULL);
-    double r[NR]; const int n = s37_residual_k(c, x, u, p, k, r, NULL, &kk);
-    double s = 0; for (int i = 0; i < n; ++i) s += r[i] * r[i];
-    s37_dyn_k(c, x, u, &kk, xn);
-    return s;
-}
-static void s37_second_order(const consts_t* c, const double* x, const double* u, const double* p, const double* vp, double theta, int mode,
-                             double* Q) {
-    (void)p;
-    if (mode == 2) {
-        const double* cs[4] = {x + 7, x + 10, x + 13, x + 16}; const double* fs[4] = {u + 3, u + 9, u + 15, u + 21};
-        int gl[34];
-        for (int i = 0; i < 7; ++i) gl[i] = i;
-        for (int i = 0; i < 3; ++i) gl[7 + i] = 22 + i;
-        for (int i = 0; i < 12; ++i) gl[10 + i] = 7 + i;
-        for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) gl[22 + 3 * i + a] = 37 + 6 * i + 3 + a;
-        srbd_second_order_full(c, x, x + 3, x + 22, 4, cs, fs, vp + 3, vp + 22, gl, 3, 22, theta, Q, 61);
-        bound_second_order(c, x, u, 37, 24, theta, Q);
-        return;
-    }
-    double R[9], M[9], Mi[9], lam[3], y[3], S[9];
-    quat_to_rot(x + 3, R); world_inertia(c, R, M); inv3(M, Mi);
-    for (int a = 0; a < 3; ++a) lam[a] = c->dt * vp[22 + a];
-    mv3(Mi, lam, y); skew(y, S);
-    for (int i = 0; i < 4; ++i) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
-        const double v = theta * c->lever * S[3 * a + b];
-        const int uf = 37 + 6 * i + 3 + a;
-        Q[uf * 61 + b] -= v; Q[b * 61 + uf] -= v;                               /* d2 / df dr */
-        Q[uf * 61 + 7 + 3 * i + b] += v; Q[(7 + 3 * i + b) * 61 + uf] += v;     /* d2 / df dc_i */
-    }
-}
-#include "ddp_engine.inc"
-#undef NX
-#undef NU
-#undef NP
+#include "srbd_cs.inc"
+#undef NCC
+#undef NR
+#undef MDL
+#define NCC 8
+#define NR 169 /* 15 state + 30 min_qddot + 48 force (+ 40 barrier) + 36 penalty rows (12 relative-velocity + 24); no bound rows */
+#define MDL(n) s61_##n
+#include "srbd_cs.inc"
+#undef NCC
 #undef NR
 #undef MDL
 
@@ -663,7 +555,7 @@ static int l30_residual(const consts_t* c, const double* x, const double* u, con
         n += 15;
         double cref[4], sw[4];
         for (int i = 0; i < 4; ++i) { cref[i] = p[3 + 2 * i]; sw[i] = p[4 + 2 * i]; }
-        n = contact_penalty_rows(x, L30_C, L30_CD, cref, sw, r, J, nz, n);
+        n = contact_penalty_rows(x, 4, L30_C, L30_CD, cref, sw, r, J, nz, n);
     }
     return n;
 }
@@ -684,13 +576,14 @@ static void l30_second_order(const consts_t* c, const double* x, const double* u
 #undef NR
 #undef MDL
 
-/* ---- exported entry points: model 0 srbd13, 1 srbd37, 2 lip30 (ids of include/sddp.h) ------------------------------------ */
+/* ---- exported entry points: model 0 srbd13, 1 srbd37, 2 lip30, 3 srbd61 (ids of include/sddp.h) ------------------------------------ */
 int oracle_solve_batch(int model, const double* cpack, int N, int B, const double* x0, const double* P, double* xs, double* us,
                        const double* o, double* stats, int threads) {
     switch (model) {
         case 0: return s13_solve_batch(cpack, N, B, x0, P, xs, us, o, stats, threads);
         case 1: return s37_solve_batch(cpack, N, B, x0, P, xs, us, o, stats, threads);
         case 2: return l30_solve_batch(cpack, N, B, x0, P, xs, us, o, stats, threads);
+        case 3: return s61_solve_batch(cpack, N, B, x0, P, xs, us, o, stats, threads);
     }
     return -1;
 }
@@ -700,6 +593,7 @@ int oracle_eval(int model, const double* cpack, const double* x, const double* u
         case 0: return s13_eval(cpack, x, u, p, k, terminal, f, F, H, g, L);
         case 1: return s37_eval(cpack, x, u, p, k, terminal, f, F, H, g, L);
         case 2: return l30_eval(cpack, x, u, p, k, terminal, f, F, H, g, L);
+        case 3: return s61_eval(cpack, x, u, p, k, terminal, f, F, H, g, L);
     }
     return -1;
 }

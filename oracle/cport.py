@@ -7,11 +7,11 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SRC = [os.path.join(_HERE, "c", "sddp_oracle.c"), os.path.join(_HERE, "c", "ddp_engine.inc")]
+_SRC = [os.path.join(_HERE, "c", f) for f in ("sddp_oracle.c", "ddp_engine.inc", "srbd_cs.inc")]
 _lib = None
 
-MODEL_IDS = {"srbd13": 0, "srbd37": 1, "lip30": 2}
-DIMS = {"srbd13": (13, 6, 19), "srbd37": (37, 24, 19), "lip30": (30, 15, 11)}
+MODEL_IDS = {"srbd13": 0, "srbd37": 1, "lip30": 2, "srbd61": 3}
+DIMS = {"srbd13": (13, 6, 19), "srbd37": (37, 24, 19), "lip30": (30, 15, 11), "srbd61": (61, 48, 27)}
 
 
 def _host_tag():
@@ -37,13 +37,15 @@ def load():
     return _lib
 
 
-def pack_consts(cst):
-    """cst: oracle.models.RobotConsts"""
+def pack_consts(cst, model=None):
+    """cst: oracle.models.RobotConsts.  The packed record holds contact points 0..3 -- all the problem graphs use (d_initial_1/2,
+    prb.py:153-154); srbd61's eight points live in cst.feet8, whose first four take that place."""
+    feet = np.asarray(cst.feet8 if model == "srbd61" else cst.feet, dtype=float).reshape(-1)[:12]
     return np.array([cst.m, *np.asarray(cst.I, dtype=float).reshape(-1), cst.com[2], cst.dt, cst.force_scaling,
                      cst.r_tracking_gain, cst.rdot_tracking_gain, cst.w_tracking_gain, cst.force_switch_weight,
                      cst.min_qddot_gain, cst.min_f_gain, float(cst.inertia_mode), cst.lever_sign,
                      cst.friction_cone_coefficient, cst.friction_barrier_weight, cst.friction_barrier_sharpness,
-                     cst.rel_pos_gain, cst.zmp_tracking_gain, cst.lip_height, *np.asarray(cst.feet, dtype=float).reshape(-1),
+                     cst.rel_pos_gain, cst.zmp_tracking_gain, cst.lip_height, *feet,
                      cst.bound_barrier_weight, cst.bound_barrier_sharpness, *_bounds64(cst.lower, -np.inf), *_bounds64(cst.upper, np.inf)],
                     dtype=np.float64)
 
@@ -78,7 +80,7 @@ def solve_batch(cst, opts, x0, P, xs, us, threads=1, model="srbd13"):
     P = np.ascontiguousarray(P, dtype=np.float64)
     assert xs.shape == (B, N + 1, nx) and us.shape == (B, N, nu) and x0.shape == (B, nx) and P.shape == (B, N + 1, npar)
     stats = np.zeros((B, 7))
-    cp, op = pack_consts(cst), pack_opts(opts)
+    cp, op = pack_consts(cst, model), pack_opts(opts)
     rc = lib.oracle_solve_batch(C.c_int(MODEL_IDS[model]), _p(cp), C.c_int(N), C.c_int(B), _p(x0), _p(P), _p(xs), _p(us), _p(op),
                                 _p(stats), C.c_int(threads))
     assert rc == 0
@@ -90,7 +92,7 @@ def eval_knot(cst, x, u, p, k, terminal, model="srbd13"):
     nx, nu, _ = DIMS[model]
     nz = nx + nu
     f = np.zeros(nx); F = np.zeros((nx, nz)); H = np.zeros((nz, nz)); g = np.zeros(nz); L = np.zeros(1)
-    cp = pack_consts(cst)
+    cp = pack_consts(cst, model)
     x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64); p = np.ascontiguousarray(p, dtype=np.float64)
     rc = lib.oracle_eval(C.c_int(MODEL_IDS[model]), _p(cp), _p(x), _p(u), _p(p), C.c_int(k), C.c_int(int(terminal)), _p(f), _p(F), _p(H),
                          _p(g), _p(L))

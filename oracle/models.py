@@ -5,9 +5,10 @@ Upstream formulas that live in absent third-party packages (Horizon ``utils.toRo
 ``utils.double_integrator_with_floating_base``, ``utils.quaterion_product``) are restated from their
 published definitions and tagged UPSTREAM-UNVERIFIED.
 
-Three models:
+Four models:
   * ``srbd13``  nx=13 nu=6  np=19 -- the BASELINE.json metric model
-  * ``srbd37``  nx=37 nu=24 np=19 -- the reference-faithful SRBD problem (prb.py:16-246)
+  * ``srbd37``  nx=37 nu=24 np=19 -- the reference-faithful SRBD problem (prb.py:16-246) at the launch file's contact_model = 2
+  * ``srbd61``  nx=61 nu=48 np=27 -- the same problem at the code's default contact_model = 4 (prb.py:39-41)
   * ``lip30``   nx=30 nu=15 np=11 -- the reference LIP problem (prb.py:248-441)
 
 Costs follow ddp.py:179-226: stage L_k = sum ||residual||^2 + 1e6 * sum ||eq-constraint||^2, terminal
@@ -37,6 +38,10 @@ class RobotConsts:
     # nc=4 line feet: left upper/lower, right upper/lower (launch:24-25)
     feet: np.ndarray = field(default_factory=lambda: np.array(
         [[0.08, 0.1, 0.0], [-0.08, 0.1, 0.0], [0.08, -0.1, 0.0], [-0.08, -0.1, 0.0]]))
+    # nc=8 (contact_model = 4): the four corners of the left sole, then of the right one
+    feet8: np.ndarray = field(default_factory=lambda: np.array(
+        [[0.08, 0.13, 0.0], [-0.08, 0.13, 0.0], [0.08, 0.07, 0.0], [-0.08, 0.07, 0.0],
+         [0.08, -0.07, 0.0], [-0.08, -0.07, 0.0], [0.08, -0.13, 0.0], [-0.08, -0.13, 0.0]]))
     dt: float = 0.05                                                 # T/ns, prb.py:110 ; wpg.py:20
     force_scaling: float = 1000.0                                    # prb.py:98
     r_tracking_gain: float = 1e3                                     # prb.py:142
@@ -578,16 +583,17 @@ def _rel_pos_rows(rows, c, cs, c_idx, feet):
 
 
 # ----------------------------------------------------------------------------------------------------------
-# srbd37 -- reference-faithful SRBD (prb.py:16-246), nc = 4
+# srbd37 / srbd61 -- reference-faithful SRBD (prb.py:16-246), contacts are states; nc = number_of_legs * contact_model
+# (prb.py:39-41): 4 (the launch file's contact_model = 2) and 8 (the default in the code, contact_model = 4)
 # ----------------------------------------------------------------------------------------------------------
 class SRBD37(Model):
     name = "srbd37"
-    nx, nu, np_ = 37, 24, 19
     nc, contact_model = 4, 2                                                        # launch:16-17
+    nx, nu, np_ = 37, 24, 19
     R_, O_, RD_, W_ = slice(0, 3), slice(3, 7), slice(19, 22), slice(22, 25)
     C_IDX = [7, 10, 13, 16]
     CD_IDX = [25, 28, 31, 34]
-    # p = rdot_ref | w_ref | otg | (c_ref_i, sw_i) x4 | oref   (creation order)
+    # p = rdot_ref | w_ref | otg | (c_ref_i, sw_i) x nc | oref   (creation order)
     P_RDREF, P_WREF, P_OTG, P_OREF = slice(0, 3), slice(3, 6), 6, slice(15, 19)
 
     @staticmethod
@@ -598,11 +604,16 @@ class SRBD37(Model):
     def p_sw(i):
         return 8 + 2 * i
 
+    def feet(self):
+        """contact points 0..nc-1 (prb.py:130-131)"""
+        return np.asarray(self.cst.feet, dtype=float)
+
     def _split(self, x, u):
+        nc = self.nc
         cs = [x[i:i + 3] for i in self.C_IDX]
         cds = [x[i:i + 3] for i in self.CD_IDX]
-        cdd = [u[6 * i:6 * i + 3] for i in range(4)]
-        fs = [u[6 * i + 3:6 * i + 6] for i in range(4)]                              # interleaved prb.py:66-68
+        cdd = [u[6 * i:6 * i + 3] for i in range(nc)]
+        fs = [u[6 * i + 3:6 * i + 6] for i in range(nc)]                             # interleaved prb.py:66-68
         return x[self.R_], x[self.O_], x[self.RD_], x[self.W_], cs, cds, cdd, fs
 
     def f(self, x, u, p):
@@ -616,12 +627,12 @@ class SRBD37(Model):
         dt = self.cst.dt
         J = srbd_acc_jac(self.cst, r, o, w, cs, fs)
         Jo, Jw = quat_rate_jac(o, w)
-        A = np.zeros((37, 37))
-        B = np.zeros((37, 24))
+        A = np.zeros((self.nx, self.nx))
+        B = np.zeros((self.nx, self.nu))
         A[self.R_, self.RD_] = np.eye(3)
         A[self.O_, self.O_] = Jo
         A[self.O_, self.W_] = Jw
-        for i in range(4):
+        for i in range(self.nc):
             A[self.C_IDX[i]:self.C_IDX[i] + 3, self.CD_IDX[i]:self.CD_IDX[i] + 3] = np.eye(3)
             A[self.W_, self.C_IDX[i]:self.C_IDX[i] + 3] = J["wdot_c"][i]
             B[self.RD_, 6 * i + 3:6 * i + 6] = J["rddot_f"] * np.eye(3)
@@ -630,11 +641,12 @@ class SRBD37(Model):
         A[self.W_, self.R_] = J["wdot_r"]
         A[self.W_, self.O_] = J["wdot_o"]
         A[self.W_, self.W_] = J["wdot_w"]
-        return np.eye(37) + dt * A, dt * B
+        return np.eye(self.nx) + dt * A, dt * B
 
     def residual_jac(self, x, u, p, k):
         c = self.cst
-        rows = _Rows(37, 24)
+        nc, nx, nu = self.nc, self.nx, self.nu
+        rows = _Rows(nx, nu)
         terminal = u is None
         xs = x
         r, o, rd, w = xs[self.R_], xs[self.O_], xs[self.RD_], xs[self.W_]
@@ -643,63 +655,80 @@ class SRBD37(Model):
         if terminal or k >= 1:
             _srbd_state_rows(rows, c, r, o, rd, w, p[self.P_RDREF], p[self.P_WREF], p[self.P_OTG],
                              p[self.P_OREF], self.R_, self.O_, self.RD_, self.W_)
-            _rel_pos_rows(rows, c, cs, self.C_IDX, np.asarray(c.feet))
+            _rel_pos_rows(rows, c, cs, self.C_IDX, self.feet())
         if not terminal:
-            cdd = [u[6 * i:6 * i + 3] for i in range(4)]
-            fs = [u[6 * i + 3:6 * i + 6] for i in range(4)]
+            cdd = [u[6 * i:6 * i + 3] for i in range(nc)]
+            fs = [u[6 * i + 3:6 * i + 6] for i in range(nc)]
             rddot, wdot = srbd_acc(c, r, o, w, cs, fs)
             J = srbd_acc_jac(c, r, o, w, cs, fs)
             g = np.sqrt(c.min_qddot_gain)
-            Jx = np.zeros((18, 37))
-            Ju = np.zeros((18, 24))
+            Jx = np.zeros((6 + 3 * nc, nx))
+            Ju = np.zeros((6 + 3 * nc, nu))
             Jx[3:6, self.R_] = J["wdot_r"]
             Jx[3:6, self.O_] = J["wdot_o"]
             Jx[3:6, self.W_] = J["wdot_w"]
-            for i in range(4):
+            for i in range(nc):
                 Jx[3:6, self.C_IDX[i]:self.C_IDX[i] + 3] = J["wdot_c"][i]
                 Ju[0:3, 6 * i + 3:6 * i + 6] = J["rddot_f"] * np.eye(3)
                 Ju[3:6, 6 * i + 3:6 * i + 6] = J["wdot_f"][i]
                 Ju[6 + 3 * i:9 + 3 * i, 6 * i:6 * i + 3] = np.eye(3)
             rows.add(g * np.concatenate([rddot, wdot] + cdd), g * Jx, g * Ju)       # min_qddot prb.py:200
-            for i in range(4):
+            for i in range(nc):
                 _force_rows(rows, c, fs[i], p[self.p_sw(i)], 6 * i + 3)
-            _contact_penalty_rows(rows, cs, cds, [p[self.p_cref(i)] for i in range(4)],
-                                  [p[self.p_sw(i)] for i in range(4)], self.C_IDX, self.CD_IDX, self.contact_model)
+            _contact_penalty_rows(rows, cs, cds, [p[self.p_cref(i)] for i in range(nc)],
+                                  [p[self.p_sw(i)] for i in range(nc)], self.C_IDX, self.CD_IDX, self.contact_model)
             _bound_rows(rows, c, xs, u)
         return rows.stack()
 
     def second_order_ux(self, x, u, p, vp):
         M, _ = world_inertia(self.cst, x[self.O_])
         y = np.linalg.solve(M, self.cst.dt * vp[self.W_])
-        S = np.zeros((24, 37))
-        for i in range(4):
+        S = np.zeros((self.nu, self.nx))
+        for i in range(self.nc):
             S[6 * i + 3:6 * i + 6, self.R_] = -self.cst.lever_sign * skew(y)
             S[6 * i + 3:6 * i + 6, self.C_IDX[i]:self.C_IDX[i] + 3] = self.cst.lever_sign * skew(y)
         return S
 
     def second_order_full(self, x, u, p, k, vp):
         r, o, rd, w, cs, cds, cdd, fs = self._split(x, u)
-        S = _srbd_second_order_full(self.cst, 61, r, o, w, cs, fs, vp[self.O_], vp[self.W_], self.O_.start, self.W_.start,
-                                    self.C_IDX, [37 + 6 * i + 3 for i in range(4)])
+        S = _srbd_second_order_full(self.cst, self.nx + self.nu, r, o, w, cs, fs, vp[self.O_], vp[self.W_], self.O_.start, self.W_.start,
+                                    self.C_IDX, [self.nx + 6 * i + 3 for i in range(self.nc)])
         return S + np.diag(_bound_hess_extra(self.cst, x, u))
 
     def initial_state(self):
-        feet = np.asarray(self.cst.feet)
-        return np.concatenate([self.cst.com, [0, 0, 0, 1.0], feet.reshape(-1), np.zeros(18)])   # prb.py:224-240
+        # prb.py:224-240 (written out for 4 contact points there; the same pattern for nc: com, identity, feet, zero velocities)
+        return np.concatenate([self.cst.com, [0, 0, 0, 1.0], self.feet().reshape(-1), np.zeros(6 + 3 * self.nc)])
 
     def static_input(self):
-        fz = self.cst.m * GRAVITY / self.cst.force_scaling / 4                      # prb.py:242-246
-        return np.tile([0, 0, 0, 0, 0, fz], 4)
+        # prb.py:242-246 writes m g / force_scaling / 4 for its 4 contact points: the weight shared by the contact points
+        fz = self.cst.m * GRAVITY / self.cst.force_scaling / self.nc
+        return np.tile([0, 0, 0, 0, 0, fz], self.nc)
 
     def default_params(self, N):
-        P = np.zeros((N + 1, 19))
+        P = np.zeros((N + 1, self.np_))
         P[:, self.P_OTG] = 1e1
-        feet = np.asarray(self.cst.feet)
-        for i in range(4):
+        feet = self.feet()
+        for i in range(self.nc):
             P[:, self.p_cref(i)] = feet[i][2]                                       # prb.py:161
             P[:, self.p_sw(i)] = 1.0                                                # prb.py:163
         P[:, self.P_OREF] = [-0.0, -0.0, -0.0, 1.0]
         return P
+
+
+class SRBD61(SRBD37):
+    """contact_model = 4, number_of_legs = 2 (the defaults of prb.py:39-40): nc = 8 -- contact points 0..3 on the left foot,
+    4..7 on the right one.  Everything prb.py builds scales with nc except the rel_pos residuals, which name the contact points
+    0, 2 and 1, 3 literally (prb.py:153-154, :192-199: with nc = 8 all four sit on the left foot; restated as written)."""
+    name = "srbd61"
+    nc, contact_model = 8, 4
+    nx, nu, np_ = 61, 48, 27
+    R_, O_, RD_, W_ = slice(0, 3), slice(3, 7), slice(31, 34), slice(34, 37)
+    C_IDX = [7 + 3 * i for i in range(8)]
+    CD_IDX = [37 + 3 * i for i in range(8)]
+    P_RDREF, P_WREF, P_OTG, P_OREF = slice(0, 3), slice(3, 6), 6, slice(23, 27)
+
+    def feet(self):
+        return np.asarray(self.cst.feet8, dtype=float)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -797,7 +826,7 @@ class LIP30(Model):
         return P
 
 
-MODELS = {"srbd13": SRBD13, "srbd37": SRBD37, "lip30": LIP30}
+MODELS = {"srbd13": SRBD13, "srbd37": SRBD37, "lip30": LIP30, "srbd61": SRBD61}
 
 
 def make_model(name: str, cst: RobotConsts | None = None) -> Model:

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("SDDP_LIB", os.path.join(_HERE, "libsddp_hip.so"))   #
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 
-MODEL_IDS = {"srbd13": 0, "srbd37": 1, "lip30": 2}
+MODEL_IDS = {"srbd13": 0, "srbd37": 1, "lip30": 2, "srbd61": 3}
 
 
 class SddpOptions(C.Structure):
@@ -85,6 +85,7 @@ SYMBOLS = {
     "sddp_queue_info": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "sddp_fetch": (C.c_int, [_vp, _vp, _vp, _vp]),
     "sddp_synchronize": (C.c_int, [_vp]),
+    "sddp_kernel_info": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_char_p)]),
     "sddp_device_ptr": (C.c_int, [_vp, C.c_int, _P(_vp), _P(C.c_longlong)]),
     "sddp_last_kernel_ms": (C.c_int, [_vp, _P(C.c_double)]),
     "sddp_enable_timing": (C.c_int, [_vp, C.c_int]),
@@ -97,21 +98,64 @@ SYMBOLS = {
 _lib = None
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/sddp_api.hip for gfx950 into libsddp_hip.so (in-tree, so it travels to the GPU box)."""
-    src = os.path.join(CSRC, "sddp_api.hip")
-    sort_src = os.path.join(CSRC, "sddp_sort.hip")
-    deps = [src, sort_src, os.path.join(CSRC, "sddp_kernels.hpp"), os.path.join(CSRC, "sddp_kernels_mw.hpp"), os.path.join(CSRC, "sddp_models.hpp"),
-            os.path.join(CSRC, "sddp_sort.hpp"), os.path.join(INCLUDE, "sddp.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+# model builds of the library: (accessor suffix, device model type, model name).  One translation unit each (csrc/sddp_inst.hip).
+INSTANCES = [
+    ("srbd13", "Srbd13", "srbd13"), ("srbd13_b", "Srbd13B", "srbd13"), ("srbd13_s", "Srbd13S", "srbd13"), ("srbd13_bs", "Srbd13BS", "srbd13"),
+    ("srbd37", "Srbd37", "srbd37"), ("srbd37_b", "Srbd37B", "srbd37"), ("srbd37_s", "Srbd37S", "srbd37"), ("srbd37_bs", "Srbd37BS", "srbd37"),
+    ("lip30", "Lip30", "lip30"), ("srbd61", "Srbd61", "srbd61"),
+]
+HEADERS = ["sddp_kernels.hpp", "sddp_kernels_mw.hpp", "sddp_models.hpp", "sddp_sort.hpp", "sddp_handle.hpp", "sddp_launch.hpp", "sddp_kernels_host.hpp"]
+
+
+def _newer(target: str, deps) -> bool:
+    return os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, only=None) -> str:
+    """Compile the HIP library for gfx950 into libsddp_hip.so (in-tree, so it travels to the GPU box): the host API
+    (csrc/sddp_api.hip), the queue sort (csrc/sddp_sort.hip) and one object per model build (csrc/sddp_inst.hip x INSTANCES),
+    compiled in parallel and linked.  Objects live in build/obj (git-ignored); only stale ones are recompiled.
+    only: recompile just these model builds (development)."""
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("SDDP_CXXFLAGS", "").split()      # diagnostic builds only (-DSDDP_NO_MFMA, -DSDDP_STAMPS), with SDDP_LIB
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, "-I" + CSRC, *extra,
-           src, sort_src, "-o", LIB_PATH]
+    extra = os.environ.get("SDDP_CXXFLAGS", "").split()      # diagnostic builds only (-DSDDP_STAMPS), with SDDP_LIB
+    tag = "" if LIB_PATH.endswith("libsddp_hip.so") and not extra else "_" + str(abs(hash((LIB_PATH, tuple(extra)))) % 10**8)
+    objdir = os.path.join(ROOT, "build", "obj" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "sddp.h")]
+    base = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, *extra, "-c"]
+    jobs = []
+    for name in ("sddp_api", "sddp_sort"):
+        jobs.append((os.path.join(objdir, name + ".o"), os.path.join(CSRC, name + ".hip"), []))
+    inst = os.path.join(CSRC, "sddp_inst.hip")
+    for fn, model, mname in INSTANCES:
+        jobs.append((os.path.join(objdir, "inst_" + fn + ".o"), inst,
+                     ["-DSDDP_INST_MODEL=" + model, "-DSDDP_INST_FN=ops_" + fn, '-DSDDP_INST_NAME="' + mname + '"']))
+    todo = []
+    for obj, src, defs in jobs:
+        picked = only is not None and any(obj.endswith("inst_" + o + ".o") for o in only)
+        if force or picked or not _newer(obj, [src] + hdrs):
+            if only is not None and not picked and os.path.exists(obj) and not force:
+                continue
+            todo.append((obj, src, defs))
+    if not todo and _newer(LIB_PATH, [j[0] for j in jobs]):
+        return LIB_PATH
+
+    def compile_one(job):
+        obj, src, defs = job
+        cmd = base + defs + [src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    workers = max(1, min(len(todo), int(os.environ.get("SDDP_BUILD_JOBS", str(os.cpu_count() or 4)))))
+    if todo:
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(compile_one, todo))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[j[0] for j in jobs], "-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True)
     return LIB_PATH
 
 
@@ -135,7 +179,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.sddp_abi_version() != 7:
+    if lib.sddp_abi_version() != 8:
         raise RuntimeError("libsddp_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -166,8 +210,8 @@ def set_consts(c: SddpModelConsts, **over):
                 arr = np.asarray(v, dtype=float).reshape(-1)
                 if arr.size > len(field):
                     raise ValueError(f"{k}: at most {len(field)} values")
-                for i, a in enumerate(arr):
-                    field[i] = float(a)
+                for i in range(len(field)):              # the tail is reset: a reused struct keeps no stale bound
+                    field[i] = float(arr[i]) if i < arr.size else (-np.inf if k == "lower" else np.inf)
         elif k in ("I", "com", "feet"):
             arr = np.asarray(v, dtype=float).reshape(-1)
             field = getattr(c, k)

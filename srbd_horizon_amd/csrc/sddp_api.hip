@@ -12,91 +12,72 @@
 #include <vector>
 
 #include "sddp.h"
-#include "sddp_kernels.hpp"
-#include "sddp_kernels_mw.hpp"
-#include "sddp_models.hpp"
+#include "sddp_handle.hpp"
+#include "sddp_kernels_host.hpp"
 #include "sddp_sort.hpp"
 
 using namespace sddp;
 
-namespace {
+// the model builds of the library (sddp_inst.hip, one translation unit each; srbd_horizon_amd/_lib.py INSTANCES)
+namespace sddp {
+const ModelOps* ops_srbd13();
+const ModelOps* ops_srbd13_b();
+const ModelOps* ops_srbd13_s();
+const ModelOps* ops_srbd13_bs();
+const ModelOps* ops_srbd37();
+const ModelOps* ops_srbd37_b();
+const ModelOps* ops_srbd37_s();
+const ModelOps* ops_srbd37_bs();
+const ModelOps* ops_lip30();
+const ModelOps* ops_srbd61();
 
-thread_local std::string g_create_error;
-
-struct Dims {
-    int nx, nu, np, nrec;
-    size_t lds;
-};
-
-// bar: the friction-cone barrier build of the SRBD models, so2: the full second-order build (longer derivative records)
-bool model_dims(int id, Dims& d, bool bar = false, bool so2 = false) {
-    switch (id) {
-        case SDDP_MODEL_SRBD13: d = {Srbd13::NX, Srbd13::NU, Srbd13::NP, so2 ? (bar ? Srbd13BS::NREC : Srbd13S::NREC) : (bar ? Srbd13B::NREC : Srbd13::NREC), Lds<Srbd13>::BYTES}; return true;
-        case SDDP_MODEL_SRBD37: d = {Srbd37::NX, Srbd37::NU, Srbd37::NP, so2 ? (bar ? Srbd37BS::NREC : Srbd37S::NREC) : (bar ? Srbd37B::NREC : Srbd37::NREC), Lds<Srbd37>::BYTES}; return true;
-        case SDDP_MODEL_LIP30: d = {Lip30::NX, Lip30::NU, Lip30::NP, Lip30::NREC, Lds<Lip30>::BYTES}; return true;
-        default: return false;
-    }
+std::string& create_error() {
+    thread_local std::string e;
+    return e;
 }
 
-}  // namespace
+int launch_queue_order(sddp_handle* h, int first, int count) {
+    hipLaunchKernelGGL(queue_order_kernel, dim3(1), dim3(1024), 0, h->stream, first, count, h->hist, h->order);
+    HIP_TRY(h, hipGetLastError());
+    return SDDP_OK;
+}
 
-struct sddp_handle {
-    int model_id = 0, N = 0, B = 0;
-    Dims d{};
-    sddp_options opts{};
-    sddp_model_consts consts{};
-    DevConsts dc{};
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    // device buffers
-    double *x0 = nullptr, *P = nullptr, *xs = nullptr, *us = nullptr, *xn = nullptr, *un = nullptr, *xc = nullptr, *uc = nullptr, *dft = nullptr,
-           *gains = nullptr, *rec = nullptr, *scal = nullptr;
-    sddp_stats* stats = nullptr;
-    // timing
-    bool timing = false;
-    std::vector<hipEvent_t> ev;     // pairs (start, stop), one pair per launch since the last synchronize
-    size_t pending = 0;            // launches whose events have not been read yet
-    double last_ms = 0.0, sum_ms = 0.0;
-    long long n_ms = 0;
-    std::string err;
-    bool have_x0 = false, have_xws = false, have_uws = false, have_params = false;
-    bool bar = false;               // friction-cone barrier build (consts.friction_barrier_weight > 0)
-    bool so2 = false;               // full second-order build (opts.second_order == 2 at sddp_create)
-    double* tick_in = nullptr;      // [B][np + nx] staging of sddp_advance
-    double* step_buf = nullptr;     // [B][2 nx + nu + np] operands and result of sddp_model_step
-    char* tick_pin = nullptr;       // two pinned images of tick_in (small batches)
-    int tick_flip = 0, tick_unsynced = 0;
-    double* step_pin = nullptr;     // pinned host image of step_buf (small batches)
-    void* pinned = nullptr;         // small batches: pinned host staging of x | u | stats, so the three result copies are truly asynchronous
-    size_t pinned_bytes = 0;
-    // work queue: the solve launch runs on `slots` resident workgroups that pull instances from a queue
-    int wslots = 0;                 // slots the work buffers (xn un xc uc dft gains rec) are allocated for = min(B, resident capacity)
-    int cus = 0;
-    int* qhead = nullptr;           // device queue head
-    int* order = nullptr;           // [B] queue order of the next launch
-    int* hist = nullptr;            // [B] iterations of each instance's previous solve (-1: none)
-    // cold-queue order (queue_order = 2): initial-cost keys of the launch, their sorted copy, the unsorted index list, sort scratch
-    double *qkey = nullptr, *qkey2 = nullptr;
-    int* order_in = nullptr;
-    void* sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
-    bool gains_by_instance = false; // the last solve launch ran instance b on slot b (no queue, first = 0): sddp_device_ptr(3)
-    struct KInfo { const void* fn = nullptr; int slots = 0; };
-    KInfo kinfo[2];                 // per kernel build: dynamic-LDS attribute set, resident workgroups on this device
-    int last_grid = 0, last_queued = 0;
-    double* box_dev = nullptr;      // lower[64] | upper[64] of the bound barrier (barrier builds)
-    double* first_dev = nullptr;    // [B][nu + nx + 3] packed first knots of sddp_solve_resident_first, and its pinned host image
-    double* first_pin = nullptr;
-    char* up_pin = nullptr;         // pinned ring for small host->device uploads of the setters (no wait per call)
-    size_t up_off = 0;
-
-    size_t n_x() const { return size_t(B) * (N + 1) * d.nx; }
-    size_t n_u() const { return size_t(B) * N * d.nu; }
-    size_t n_p() const { return size_t(B) * (N + 1) * d.np; }
-    size_t n_g() const { return size_t(B) * N * d.nu * (d.nx + 1); }
-};
+int alloc_cold_queue(sddp_handle* h) {
+    if (h->sort_tmp) return SDDP_OK;               // the last pointer of the group: set only when all of it exists
+    double *k1 = nullptr, *k2 = nullptr;
+    int* oi = nullptr;
+    void* tmp = nullptr;
+    size_t tb = 0;
+    hipError_t e = hipMalloc((void**)&k1, size_t(h->B) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&k2, size_t(h->B) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&oi, size_t(h->B) * sizeof(int));
+    if (e == hipSuccess) e = sort_pairs_desc_temp_bytes(h->B, &tb);
+    if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tb, 16));
+    if (e != hipSuccess) {
+        if (k1) (void)hipFree(k1);
+        if (k2) (void)hipFree(k2);
+        if (oi) (void)hipFree(oi);
+        return fail(h, SDDP_ERR_HIP, std::string("cold-queue buffers: ") + hipGetErrorString(e));
+    }
+    h->qkey = k1; h->qkey2 = k2; h->order_in = oi; h->sort_tmp_bytes = tb; h->sort_tmp = tmp;
+    return SDDP_OK;
+}
+}  // namespace sddp
 
 namespace {
+
+// bar: the barrier build of the SRBD models (friction cone and / or variable bounds), so2: the full second-order build
+const ModelOps* model_ops(int id, bool bar = false, bool so2 = false) {
+    switch (id) {
+        case SDDP_MODEL_SRBD13: return so2 ? (bar ? ops_srbd13_bs() : ops_srbd13_s()) : (bar ? ops_srbd13_b() : ops_srbd13());
+        case SDDP_MODEL_SRBD37: return so2 ? (bar ? ops_srbd37_bs() : ops_srbd37_s()) : (bar ? ops_srbd37_b() : ops_srbd37());
+        case SDDP_MODEL_LIP30: return ops_lip30();
+        case SDDP_MODEL_SRBD61: return (bar || so2) ? nullptr : ops_srbd61();
+        default: return nullptr;
+    }
+}
+// models whose only build is the default one: linear-quadratic (lip30), or no barrier / second_order = 2 build instantiated (srbd61)
+bool single_build(int id) { return id == SDDP_MODEL_LIP30; }
 
 // host scratch of a call: plain malloc (no exception can cross the C boundary), freed on every return path
 struct host_buf {
@@ -108,18 +89,6 @@ struct host_buf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-int fail(sddp_handle* h, int code, const std::string& msg) {
-    if (h) h->err = msg; else g_create_error = msg;
-    return code;
-}
-
-#define HIP_TRY(h, expr)                                                                         \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return fail(h, SDDP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
-    } while (0)
-
 SolveArgs make_args(sddp_handle* h, const double* d_params) {
     SolveArgs a;
     a.c = h->dc; a.o = h->opts; a.N = h->N; a.B = h->B;
@@ -129,175 +98,7 @@ SolveArgs make_args(sddp_handle* h, const double* d_params) {
     return a;
 }
 
-// large models (> 48 KB of LDS per instance: srbd37, lip30) run on 4 waves per instance (sddp_kernels_mw.hpp)
-template <class M>
-constexpr bool use_mw() {
-#ifdef SDDP_MW_ALL
-    return true;
-#else
-    return Lds<M>::BYTES > 48 * 1024;
-#endif
-}
-
-bool model_uses_mw(int model_id) {
-    switch (model_id) {
-        case SDDP_MODEL_SRBD13: return use_mw<Srbd13>();
-        case SDDP_MODEL_SRBD37: return use_mw<Srbd37>();
-        case SDDP_MODEL_LIP30: return use_mw<Lip30>();
-        default: return false;
-    }
-}
-
-// only the kernel a model actually uses is instantiated
-using KernelFn = void (*)(SolveArgs);
-template <class M> KernelFn pick_solve(int waves_per_simd) {
-    if constexpr (use_mw<M>()) {
-        if constexpr (2 * LdsMW<M>::BYTES <= size_t(160) * 1024) return waves_per_simd >= 2 ? solve_kernel_mw_w2<M> : solve_kernel_mw<M>;
-        else return solve_kernel_mw<M>;
-    } else return waves_per_simd >= 2 ? solve_kernel_w2<M> : solve_kernel<M>;
-}
-template <class M> KernelFn pick_backward() { if constexpr (use_mw<M>()) return backward_kernel_mw<M>; else return backward_kernel<M>; }
-template <class M> KernelFn pick_forward() { if constexpr (use_mw<M>()) return forward_kernel_mw<M>; else return forward_kernel<M>; }
-
 constexpr size_t kUpRing = size_t(256) << 10;
-
-// resident workgroups of `kern` on this device (the queue's slot count) and its dynamic-LDS attribute, once per handle and build
-template <class M>
-int kernel_slots(sddp_handle* h, KernelFn kern, int* slots) {
-    constexpr bool MW = use_mw<M>();
-    constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
-    constexpr int threads = MW ? kThreadsMW : kWave;
-    for (auto& k : h->kinfo)
-        if (k.fn == reinterpret_cast<const void*>(kern)) { *slots = k.slots; return SDDP_OK; }
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 0;
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
-    if (!MW) per_cu = std::min(per_cu, 4 * (h->opts.waves_per_simd >= 2 ? 2 : 1));   // the two builds: 1 or 2 wavefronts per SIMD
-    per_cu = std::max(1, std::min(per_cu, 32));
-    auto& k = h->kinfo[h->kinfo[0].fn ? 1 : 0];
-    k.fn = reinterpret_cast<const void*>(kern);
-    k.slots = per_cu * std::max(1, h->cus);
-    *slots = k.slots;
-    return SDDP_OK;
-}
-
-// one launch over the instances [first, first + count): grid = resident slots, at most `count` and at most the slots the work
-// buffers exist for; more instances than slots -> work queue, in longest-previous-solve-first order when opts.queue_order is set
-template <class M>
-int launch_solve(sddp_handle* h, SolveArgs a, int first, int count) {
-    constexpr bool MW = use_mw<M>();
-    KernelFn kern = pick_solve<M>(h->opts.waves_per_simd);
-    constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
-    constexpr int threads = MW ? kThreadsMW : kWave;
-    int slots = 0;
-    int rc = kernel_slots<M>(h, kern, &slots);
-    if (rc != SDDP_OK) return rc;
-    if constexpr (MW) {   // a half-register-file build that the device still runs one per CU (barrier builds) has nothing to offer
-        if (h->opts.waves_per_simd >= 2) {
-            KernelFn k1 = pick_solve<M>(1);
-            int s1 = 0;
-            rc = kernel_slots<M>(h, k1, &s1);
-            if (rc != SDDP_OK) return rc;
-            if (s1 >= slots) { kern = k1; slots = s1; }
-        }
-    }
-    int grid = std::min(count, std::min(slots, h->wslots));
-    if (h->opts.max_slots > 0) grid = std::min(grid, h->opts.max_slots);
-    a.first = first; a.count = count;
-    if (count > grid) {
-        HIP_TRY(h, hipMemsetAsync(h->qhead, 0, sizeof(int), h->stream));
-        a.qhead = h->qhead;
-        if (h->opts.queue_order == 1) {            // longest previous solve first
-            hipLaunchKernelGGL(queue_order_kernel, dim3(1), dim3(1024), 0, h->stream, first, count, h->hist, h->order);
-            HIP_TRY(h, hipGetLastError());
-            a.order = h->order;
-        } else if (h->opts.queue_order == 2) {     // largest initial cost first: keys by a pre-pass over the launch's instances
-            if (!h->qkey) {
-                HIP_TRY(h, hipMalloc((void**)&h->qkey, size_t(h->B) * sizeof(double)));
-                HIP_TRY(h, hipMalloc((void**)&h->qkey2, size_t(h->B) * sizeof(double)));
-                HIP_TRY(h, hipMalloc((void**)&h->order_in, size_t(h->B) * sizeof(int)));
-                HIP_TRY(h, sort_pairs_desc_temp_bytes(h->B, &h->sort_tmp_bytes));
-                HIP_TRY(h, hipMalloc(&h->sort_tmp, std::max<size_t>(h->sort_tmp_bytes, 16)));
-            }
-            hipLaunchKernelGGL(queue_cost_key_kernel<M>, dim3(count), dim3(kWave), 0, h->stream, a.c, a.N, first, count, a.x0, a.P, a.xs,
-                               a.us, h->qkey, h->order_in);
-            HIP_TRY(h, hipGetLastError());
-            HIP_TRY(h, sort_pairs_desc(h->sort_tmp, h->sort_tmp_bytes, h->qkey, h->qkey2, h->order_in, h->order, count, h->stream));
-            a.order = h->order;
-        }
-    }
-    h->last_grid = grid; h->last_queued = count > grid ? count : 0;
-    h->gains_by_instance = (count <= grid && first == 0);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->timing) {
-        while (h->ev.size() < 2 * (h->pending + 1)) {
-            hipEvent_t e;
-            HIP_TRY(h, hipEventCreate(&e));
-            try { h->ev.push_back(e); } catch (...) { (void)hipEventDestroy(e); return fail(h, SDDP_ERR_NOMEM, "out of host memory"); }
-        }
-        e0 = h->ev[2 * h->pending];
-        e1 = h->ev[2 * h->pending + 1];
-        HIP_TRY(h, hipEventRecord(e0, h->stream));
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, h->stream, a);
-    HIP_TRY(h, hipGetLastError());
-    if (h->timing) {
-        HIP_TRY(h, hipEventRecord(e1, h->stream));
-        ++h->pending;
-    }
-    return SDDP_OK;
-}
-// resident capacity over the builds a handle may switch between (sddp_set_options): sizes the work buffers
-template <class M>
-int max_slots(sddp_handle* h, int* slots) {
-    if constexpr (use_mw<M>() && 2 * LdsMW<M>::BYTES > size_t(160) * 1024) return kernel_slots<M>(h, pick_solve<M>(1), slots);
-    else {
-        const int keep = h->opts.waves_per_simd;
-        int s1 = 0, s2 = 0;
-        h->opts.waves_per_simd = 1;
-        int rc = kernel_slots<M>(h, pick_solve<M>(1), &s1);
-        h->opts.waves_per_simd = 2;
-        if (rc == SDDP_OK) rc = kernel_slots<M>(h, pick_solve<M>(2), &s2);
-        h->opts.waves_per_simd = keep;
-        *slots = std::max(s1, s2);
-        return rc;
-    }
-}
-template <class M>
-int launch_backward(sddp_handle* h, const SolveArgs& a) {
-    constexpr bool MW = use_mw<M>();
-    KernelFn kern = pick_backward<M>();
-    constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(h->B), dim3(MW ? kThreadsMW : kWave), lds, h->stream, a);
-    HIP_TRY(h, hipGetLastError());
-    return SDDP_OK;
-}
-template <class M>
-int launch_forward(sddp_handle* h, const SolveArgs& a) {
-    constexpr bool MW = use_mw<M>();
-    KernelFn kern = pick_forward<M>();
-    constexpr size_t lds = MW ? LdsMW<M>::BYTES : Lds<M>::BYTES;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(h->B), dim3(MW ? kThreadsMW : kWave), lds, h->stream, a);
-    HIP_TRY(h, hipGetLastError());
-    return SDDP_OK;
-}
-
-template <class M>
-int launch_model_step(sddp_handle* h, int k, const double* dx, const double* du, const double* dp, double* dxn) {
-    hipLaunchKernelGGL(model_step_kernel<M>, dim3((h->B + kWave - 1) / kWave), dim3(kWave), 0, h->stream, h->dc, h->B, k, dx, du, dp, dxn);
-    HIP_TRY(h, hipGetLastError());
-    return SDDP_OK;
-}
-
-#define DISPATCH(h, fn, ...)                                                 \
-    switch ((h)->model_id) {                                                 \
-        case SDDP_MODEL_SRBD13: rc = (h)->so2 ? ((h)->bar ? fn<Srbd13BS>(__VA_ARGS__) : fn<Srbd13S>(__VA_ARGS__)) : ((h)->bar ? fn<Srbd13B>(__VA_ARGS__) : fn<Srbd13>(__VA_ARGS__)); break; \
-        case SDDP_MODEL_SRBD37: rc = (h)->so2 ? ((h)->bar ? fn<Srbd37BS>(__VA_ARGS__) : fn<Srbd37S>(__VA_ARGS__)) : ((h)->bar ? fn<Srbd37B>(__VA_ARGS__) : fn<Srbd37>(__VA_ARGS__)); break; \
-        case SDDP_MODEL_LIP30: rc = fn<Lip30>(__VA_ARGS__); break;            \
-        default: rc = SDDP_ERR_MODEL;                                         \
-    }
 
 int check_ready(sddp_handle* h) {
     if (!h) return SDDP_ERR_ARG;
@@ -340,8 +141,9 @@ extern "C" {
 int sddp_abi_version(void) { return SDDP_ABI_VERSION; }
 
 int sddp_model_dims(int model_id, int* nx, int* nu, int* np) {
-    Dims d;
-    if (!model_dims(model_id, d)) return SDDP_ERR_MODEL;
+    const ModelOps* ops = model_ops(model_id);
+    if (!ops) return SDDP_ERR_MODEL;
+    const Dims d = ops->dims;
     if (nx) *nx = d.nx;
     if (nu) *nu = d.nu;
     if (np) *np = d.np;
@@ -391,18 +193,20 @@ void sddp_default_consts(sddp_model_consts* c) {
     for (int i = 0; i < 64; ++i) { c->lower[i] = -HUGE_VAL; c->upper[i] = HUGE_VAL; }
 }
 
-const char* sddp_last_error(const sddp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+const char* sddp_last_error(const sddp_handle* h) { return h ? h->err.c_str() : create_error().c_str(); }
 
 int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_options* opts, const sddp_model_consts* consts) {
     if (!out) return fail(nullptr, SDDP_ERR_ARG, "out is NULL");
     *out = nullptr;
-    Dims d;
+    if (!model_ops(model_id)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
     if (consts && consts->bound_barrier_weight > 0.0 && model_id == SDDP_MODEL_LIP30)
         return fail(nullptr, SDDP_ERR_ARG, "bound_barrier_weight > 0: the bound barrier exists for the SRBD models only");
     // barrier builds: the friction-cone barrier and / or the bound barrier
-    const bool bar = consts && (consts->friction_barrier_weight > 0.0 || consts->bound_barrier_weight > 0.0) && model_id != SDDP_MODEL_LIP30;
-    const bool so2 = opts && opts->second_order == 2 && model_id != SDDP_MODEL_LIP30;     // (the LIP model is linear-quadratic: nothing to add)
-    if (!model_dims(model_id, d, bar, so2)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
+    const bool bar = consts && (consts->friction_barrier_weight > 0.0 || consts->bound_barrier_weight > 0.0) && !single_build(model_id);
+    const bool so2 = opts && opts->second_order == 2 && !single_build(model_id);     // (the LIP model is linear-quadratic: nothing to add)
+    const ModelOps* ops = model_ops(model_id, bar, so2);
+    if (!ops) return fail(nullptr, SDDP_ERR_ARG, "this model has no barrier / second_order = 2 build (srbd61: default build only)");
+    const Dims d = ops->dims;
     if (N < 1 || batch < 1) return fail(nullptr, SDDP_ERR_ARG, "N and batch must be >= 1");
     if (consts && (consts->friction_barrier_weight < 0.0 || (consts->friction_barrier_weight > 0.0 && !(consts->friction_cone_coefficient > 0.0))))
         return fail(nullptr, SDDP_ERR_ARG, "friction_barrier_weight must be >= 0 and friction_cone_coefficient > 0");
@@ -418,11 +222,11 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
         return fail(nullptr, SDDP_ERR_HIP, "no HIP device visible: the SDDP engine has no CPU fallback");
     sddp_handle* h = new (std::nothrow) sddp_handle();
     if (!h) return fail(nullptr, SDDP_ERR_NOMEM, "out of host memory");
-    h->model_id = model_id; h->N = N; h->B = batch; h->d = d; h->bar = bar; h->so2 = so2;
+    h->model_id = model_id; h->N = N; h->B = batch; h->d = d; h->ops = ops; h->bar = bar; h->so2 = so2;
     if (opts) h->opts = *opts; else sddp_default_options(&h->opts);
     if (consts) h->consts = *consts; else sddp_default_consts(&h->consts);
     int rc = validate_options(h, h->opts);
-    if (rc != SDDP_OK) { g_create_error = h->err; delete h; return rc; }
+    if (rc != SDDP_OK) { create_error() = h->err; delete h; return rc; }
     h->dc = make_dev_consts(h->consts);
     auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
     hipError_t e = hipSuccess;
@@ -442,8 +246,8 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     }
     // resident capacity of the solve kernel(s) on this device = number of queue slots; the work buffers exist per slot
     int slots = 0;
-    DISPATCH(h, max_slots, h, &slots);
-    if (rc != SDDP_OK) { g_create_error = h->err; delete h; return rc; }
+    rc = ops->max_slots(h, &slots);
+    if (rc != SDDP_OK) { create_error() = h->err; sddp_destroy(h); return rc; }
     h->wslots = std::min(batch, slots);
     if (h->opts.max_slots > 0) h->wslots = std::min(h->wslots, h->opts.max_slots);
     const size_t W = size_t(h->wslots);
@@ -457,7 +261,7 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (e == hipSuccess) { h->us = h->xs + h->n_x(); h->stats = reinterpret_cast<sddp_stats*>(h->us + h->n_u()); }
     if (e == hipSuccess) e = alloc((void**)&h->xn, W * (N + 1) * d.nx * D);
     if (e == hipSuccess) e = alloc((void**)&h->un, W * N * d.nu * D);
-    if (!model_uses_mw(model_id)) {   // one-wave kernel: two sets of kSlots line-search candidates per slot
+    if (!ops->uses_mw) {   // one-wave kernel: two sets of kSlots line-search candidates per slot
         if (e == hipSuccess) e = alloc((void**)&h->xc, W * (N + 1) * d.nx * 2 * kSlots * D);
         if (e == hipSuccess) e = alloc((void**)&h->uc, W * N * d.nu * 2 * kSlots * D);
     }
@@ -478,9 +282,13 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (e == hipSuccess) e = hipMemsetAsync(h->qhead, 0, sizeof(int), h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
-        g_create_error = std::string("sddp_create: ") + hipGetErrorString(e);
+        create_error() = std::string("sddp_create: ") + hipGetErrorString(e);
         sddp_destroy(h);
         return SDDP_ERR_HIP;
+    }
+    if (h->opts.queue_order == 2) {   // cold-queue order: its key / sort buffers exist before the first launch (all or nothing)
+        rc = alloc_cold_queue(h);
+        if (rc != SDDP_OK) { create_error() = h->err; sddp_destroy(h); return rc; }
     }
     *out = h;
     return SDDP_OK;
@@ -609,7 +417,7 @@ int sddp_solve_range_device(sddp_handle* h, const double* d_params, int first, i
     if (!d_params) return fail(h, SDDP_ERR_ARG, "params is NULL");
     if (first < 0 || count < 1 || first > h->B - count) return fail(h, SDDP_ERR_ARG, "instance range outside the batch");
     SolveArgs a = make_args(h, d_params);
-    DISPATCH(h, launch_solve, h, a, first, count);
+    rc = h->ops->launch_solve(h, a, first, count);
     return rc;
 }
 
@@ -623,6 +431,14 @@ int sddp_queue_info(sddp_handle* h, int* slots, int* last_grid, int* last_queued
     if (slots) *slots = h->wslots;
     if (last_grid) *last_grid = h->last_grid;
     if (last_queued) *last_queued = h->last_queued;
+    return SDDP_OK;
+}
+
+int sddp_kernel_info(sddp_handle* h, int* wavefronts_per_instance, int* last_waves_per_simd, const char** model_name) {
+    if (!h) return SDDP_ERR_ARG;
+    if (wavefronts_per_instance) *wavefronts_per_instance = h->ops->uses_mw ? 4 : 1;
+    if (last_waves_per_simd) *last_waves_per_simd = h->last_build;
+    if (model_name) *model_name = h->ops->name;
     return SDDP_OK;
 }
 
@@ -793,7 +609,7 @@ int sddp_model_step(sddp_handle* h, const double* x, const double* u, const doub
         std::memcpy(hp + B * nx, u, B * nu * D);
         std::memcpy(hp + B * (nx + nu), p, B * np * D);
         HIP_TRY(h, hipMemcpyAsync(dx, hp, B * (nx + nu + np) * D, hipMemcpyHostToDevice, h->stream));
-        DISPATCH(h, launch_model_step, h, k, dx, du, dp, dxn);
+        rc = h->ops->launch_model_step(h, k, dx, du, dp, dxn);
         if (rc != SDDP_OK) return rc;
         HIP_TRY(h, hipMemcpyAsync(hp + B * (nx + nu + np), dxn, B * nx * D, hipMemcpyDeviceToHost, h->stream));
         rc = sddp_synchronize(h);
@@ -803,7 +619,7 @@ int sddp_model_step(sddp_handle* h, const double* x, const double* u, const doub
     HIP_TRY(h, hipMemcpyAsync(dx, x, B * nx * D, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(du, u, B * nu * D, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(dp, p, B * np * D, hipMemcpyHostToDevice, h->stream));
-    DISPATCH(h, launch_model_step, h, k, dx, du, dp, dxn);
+    rc = h->ops->launch_model_step(h, k, dx, du, dp, dxn);
     if (rc != SDDP_OK) return rc;
     HIP_TRY(h, hipMemcpyAsync(x_next, dxn, B * nx * D, hipMemcpyDeviceToHost, h->stream));
     return sddp_synchronize(h);
@@ -864,63 +680,50 @@ int sddp_kernel_time_stats(sddp_handle* h, double* sum_ms, long long* count, int
 // ---- test building blocks ----------------------------------------------------------------------------------------------
 int sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk, const int* k, const double* x,
                     const double* u, const double* p, double* f_out, double* F_out, double* H_out, double* g_out, double* L_out) {
-    Dims d;
     sddp_model_consts cc;
     if (consts) cc = *consts; else sddp_default_consts(&cc);
-    const bool bar = (cc.friction_barrier_weight > 0.0 || cc.bound_barrier_weight > 0.0) && model_id != SDDP_MODEL_LIP30;
-    if (!model_dims(model_id, d, bar)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
+    if (!model_ops(model_id)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
+    const bool bar = (cc.friction_barrier_weight > 0.0 || cc.bound_barrier_weight > 0.0) && !single_build(model_id);
+    const ModelOps* ops = model_ops(model_id, bar, false);
+    if (!ops) return fail(nullptr, SDDP_ERR_ARG, "this model has no barrier build");
+    const Dims d = ops->dims;
     if (nk < 1 || !k || !x || !u || !p) return fail(nullptr, SDDP_ERR_ARG, "bad argument");
     DevConsts dc = make_dev_consts(cc);
     const int nz = d.nx + d.nu;
-    double* dbox = nullptr;
     const size_t D = sizeof(double);
-    int* dk = nullptr;
-    double *dx = nullptr, *du = nullptr, *dp = nullptr, *drec = nullptr, *df = nullptr, *dF = nullptr, *dH = nullptr, *dg = nullptr, *dL = nullptr;
-#define TRY0(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(nullptr, SDDP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+    // every device buffer of the call in one table, freed on every return path
+    enum { B_BOX, B_K, B_X, B_U, B_P, B_REC, B_F, B_FF, B_H, B_G, B_L, B_N };
+    void* buf[B_N] = {};
+    const size_t bytes[B_N] = {bar ? 128 * D : 0, nk * sizeof(int), size_t(nk) * d.nx * D, size_t(nk) * d.nu * D, size_t(nk) * d.np * D,
+                               size_t(nk) * d.nrec * D, size_t(nk) * d.nx * D, size_t(nk) * d.nx * nz * D, size_t(nk) * nz * nz * D,
+                               size_t(nk) * nz * D, size_t(nk) * D};
+    auto release = [&]() { for (void* b : buf) if (b) (void)hipFree(b); };
+#define TRY0(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { release(); return fail(nullptr, SDDP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    for (int i = 0; i < B_N; ++i)
+        if (bytes[i]) TRY0(hipMalloc(&buf[i], bytes[i]));
     if (bar) {
         double hb[128];
         for (int i = 0; i < 64; ++i) { hb[i] = cc.lower[i]; hb[64 + i] = cc.upper[i]; }
-        TRY0(hipMalloc((void**)&dbox, sizeof(hb)));
-        TRY0(hipMemcpy(dbox, hb, sizeof(hb), hipMemcpyHostToDevice));
-        dc.box = dbox;
+        TRY0(hipMemcpy(buf[B_BOX], hb, sizeof(hb), hipMemcpyHostToDevice));
+        dc.box = static_cast<double*>(buf[B_BOX]);
     }
-    TRY0(hipMalloc((void**)&dk, nk * sizeof(int)));
-    TRY0(hipMalloc((void**)&dx, size_t(nk) * d.nx * D));
-    TRY0(hipMalloc((void**)&du, size_t(nk) * d.nu * D));
-    TRY0(hipMalloc((void**)&dp, size_t(nk) * d.np * D));
-    TRY0(hipMalloc((void**)&drec, size_t(nk) * d.nrec * D));
-    TRY0(hipMalloc((void**)&df, size_t(nk) * d.nx * D));
-    TRY0(hipMalloc((void**)&dF, size_t(nk) * d.nx * nz * D));
-    TRY0(hipMalloc((void**)&dH, size_t(nk) * nz * nz * D));
-    TRY0(hipMalloc((void**)&dg, size_t(nk) * nz * D));
-    TRY0(hipMalloc((void**)&dL, size_t(nk) * D));
-    TRY0(hipMemcpy(dk, k, nk * sizeof(int), hipMemcpyHostToDevice));
-    TRY0(hipMemcpy(dx, x, size_t(nk) * d.nx * D, hipMemcpyHostToDevice));
-    TRY0(hipMemcpy(du, u, size_t(nk) * d.nu * D, hipMemcpyHostToDevice));
-    TRY0(hipMemcpy(dp, p, size_t(nk) * d.np * D, hipMemcpyHostToDevice));
-    TRY0(hipMemset(drec, 0, size_t(nk) * d.nrec * D));
-    switch (model_id) {
-        case SDDP_MODEL_SRBD13:
-            if (bar) hipLaunchKernelGGL(eval_knots_kernel<Srbd13B>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL);
-            else hipLaunchKernelGGL(eval_knots_kernel<Srbd13>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL);
-            break;
-        case SDDP_MODEL_SRBD37:
-            if (bar) hipLaunchKernelGGL(eval_knots_kernel<Srbd37B>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL);
-            else hipLaunchKernelGGL(eval_knots_kernel<Srbd37>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL);
-            break;
-        case SDDP_MODEL_LIP30: hipLaunchKernelGGL(eval_knots_kernel<Lip30>, dim3(nk), dim3(kWave), 0, 0, dc, N, nk, dk, dx, du, dp, drec, df, dF, dH, dg, dL); break;
-    }
+    TRY0(hipMemcpy(buf[B_K], k, bytes[B_K], hipMemcpyHostToDevice));
+    TRY0(hipMemcpy(buf[B_X], x, bytes[B_X], hipMemcpyHostToDevice));
+    TRY0(hipMemcpy(buf[B_U], u, bytes[B_U], hipMemcpyHostToDevice));
+    TRY0(hipMemcpy(buf[B_P], p, bytes[B_P], hipMemcpyHostToDevice));
+    TRY0(hipMemset(buf[B_REC], 0, bytes[B_REC]));
+    auto dd = [&](int i) { return static_cast<double*>(buf[i]); };
+    ops->launch_eval_knots(dc, N, nk, static_cast<const int*>(buf[B_K]), dd(B_X), dd(B_U), dd(B_P), dd(B_REC), dd(B_F), dd(B_FF), dd(B_H),
+                           dd(B_G), dd(B_L));
     TRY0(hipGetLastError());
     TRY0(hipDeviceSynchronize());
-    if (f_out) TRY0(hipMemcpy(f_out, df, size_t(nk) * d.nx * D, hipMemcpyDeviceToHost));
-    if (F_out) TRY0(hipMemcpy(F_out, dF, size_t(nk) * d.nx * nz * D, hipMemcpyDeviceToHost));
-    if (H_out) TRY0(hipMemcpy(H_out, dH, size_t(nk) * nz * nz * D, hipMemcpyDeviceToHost));
-    if (g_out) TRY0(hipMemcpy(g_out, dg, size_t(nk) * nz * D, hipMemcpyDeviceToHost));
-    if (L_out) TRY0(hipMemcpy(L_out, dL, size_t(nk) * D, hipMemcpyDeviceToHost));
-    void* bufs[] = {dk, dx, du, dp, drec, df, dF, dH, dg, dL, dbox};
-    for (void* b : bufs)
-        if (b) (void)hipFree(b);
+    if (f_out) TRY0(hipMemcpy(f_out, buf[B_F], bytes[B_F], hipMemcpyDeviceToHost));
+    if (F_out) TRY0(hipMemcpy(F_out, buf[B_FF], bytes[B_FF], hipMemcpyDeviceToHost));
+    if (H_out) TRY0(hipMemcpy(H_out, buf[B_H], bytes[B_H], hipMemcpyDeviceToHost));
+    if (g_out) TRY0(hipMemcpy(g_out, buf[B_G], bytes[B_G], hipMemcpyDeviceToHost));
+    if (L_out) TRY0(hipMemcpy(L_out, buf[B_L], bytes[B_L], hipMemcpyDeviceToHost));
 #undef TRY0
+    release();
     return SDDP_OK;
 }
 
@@ -932,7 +735,7 @@ int sddp_backward(sddp_handle* h, const double* params, double mu, double* gains
     HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     SolveArgs a = make_args(h, h->P);
     a.mu = mu;
-    DISPATCH(h, launch_backward, h, a);
+    rc = h->ops->launch_backward(h, a);
     if (rc != SDDP_OK) return rc;
     h->gains_by_instance = true;
     if (gains_out) HIP_TRY(h, hipMemcpyAsync(gains_out, h->gains, h->n_g() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -956,7 +759,7 @@ int sddp_forward(sddp_handle* h, const double* params, double alpha, double* x_o
     HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     SolveArgs a = make_args(h, h->P);
     a.alpha = alpha;
-    DISPATCH(h, launch_forward, h, a);
+    rc = h->ops->launch_forward(h, a);
     if (rc != SDDP_OK) return rc;
     if (x_out) HIP_TRY(h, hipMemcpyAsync(x_out, h->xn, h->n_x() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (u_out) HIP_TRY(h, hipMemcpyAsync(u_out, h->un, h->n_u() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

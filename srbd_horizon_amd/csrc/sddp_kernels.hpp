@@ -927,33 +927,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2))) void
     solve_queue<M>(A, s);
 }
 
-// Queue order for the next launch: instances [first, first + count) sorted by the iteration count of their previous solve,
-// longest first, never-solved ones before all others (longest-processing-time-first list scheduling: a launch ends with its
-// slowest instance, so the slow ones must start first; a fleet's robots recur tick after tick and the previous count is the
-// predictor at hand).  Counting sort in one workgroup; ties in arbitrary order (results do not depend on the order).
-constexpr int kOrderBins = 258;   // key = min(hist, 256), -1 -> 257
-__global__ __launch_bounds__(1024) void queue_order_kernel(int first, int count, const int* __restrict__ hist, int* __restrict__ order) {
-    __shared__ int bins[kOrderBins];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < kOrderBins; i += 1024) bins[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < count; i += 1024) {
-        const int h = hist[first + i];
-        atomicAdd(&bins[h < 0 ? kOrderBins - 1 : (h > 256 ? 256 : h)], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {   // exclusive prefix, largest key first
-        int run = 0;
-        for (int k = kOrderBins - 1; k >= 0; --k) { const int n = bins[k]; bins[k] = run; run += n; }
-    }
-    __syncthreads();
-    for (int i = tid; i < count; i += 1024) {
-        const int h = hist[first + i];
-        const int pos = atomicAdd(&bins[h < 0 ? kOrderBins - 1 : (h > 256 ? 256 : h)], 1);
-        order[pos] = first + i;
-    }
-}
-
 // Queue order for a COLD queue (sddp_options.queue_order = 2): the key of an instance is the total cost of its warm start
 // (x_0 := x0 as the solve does; multiple-shooting cost of the given xs / us), evaluated here by one wavefront per instance, one
 // lane per knot -- the same model code and the same sum the solve itself starts from.  The keys are then sorted in descending
@@ -1097,54 +1070,6 @@ __global__ __launch_bounds__(kWave) void forward_kernel(SolveArgs A) {
                                        A.dft + size_t(b) * N * NX, A.gains + size_t(b) * N * (NU * (NX + 1)),
                                        A.xn + size_t(b) * (N + 1) * NX, A.un + size_t(b) * N * NU, A.alpha, 0, lane, s);
     if (lane == 0) A.scal[size_t(b) * kScal] = J;
-}
-
-// what an MPC tick applies: the first input u_0 and the state the plan expects next, x_1, of every instance, packed
-// [B][nu + nx] (+ cost, iterations, status as three more doubles) for one small copy to the host instead of the whole trajectories
-__global__ __launch_bounds__(256) void first_knot_kernel(int N, int B, int nx, int nu, const double* __restrict__ xs,
-                                                         const double* __restrict__ us, const sddp_stats* __restrict__ st,
-                                                         double* __restrict__ out) {
-    const int w = nu + nx + 3;
-    for (size_t e = size_t(blockIdx.x) * 256 + threadIdx.x; e < size_t(B) * w; e += size_t(gridDim.x) * 256) {
-        const int b = int(e / w), j = int(e % w);
-        double v;
-        if (j < nu) v = us[size_t(b) * N * nu + j];
-        else if (j < nu + nx) v = xs[(size_t(b) * (N + 1) + 1) * nx + (j - nu)];
-        else v = j == nu + nx ? st[b].cost : (j == nu + nx + 1 ? double(st[b].iters) : double(st[b].status));
-        out[e] = v;
-    }
-}
-
-constexpr int kAdvanceWords = 4096;   // longest array advance_kernel shifts in one workgroup: (N+1) * max(nx, np) words
-
-// receding-horizon tick on the device: shift parameters and warm start by one knot (one workgroup per instance; every element
-// is read before the barrier and written after it, so the in-place shift is safe)
-__global__ __launch_bounds__(256) void advance_kernel(int N, int nx, int nu, int np, double* __restrict__ P, double* __restrict__ xs,
-                                                      double* __restrict__ us, double* __restrict__ x0, const double* __restrict__ p_last,
-                                                      const double* __restrict__ x0_new) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    double* Pb = P + size_t(b) * (N + 1) * np;
-    double* xb = xs + size_t(b) * (N + 1) * nx;
-    double* ub = us + size_t(b) * N * nu;
-    constexpr int R = kAdvanceWords / 256;                 // elements per thread and array
-    double rp[R], rx[R], ru[R];
-    const int np_all = (N + 1) * np, nx_all = (N + 1) * nx, nu_all = N * nu;
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-        const int e = tid + t * 256;
-        rp[t] = e < np_all ? (e + np < np_all ? Pb[e + np] : p_last[size_t(b) * np + (e - N * np)]) : 0.0;
-        rx[t] = e < nx_all ? xb[e + nx < nx_all ? e + nx : e] : 0.0;
-        ru[t] = e < nu_all ? ub[e + nu < nu_all ? e + nu : e] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-        const int e = tid + t * 256;
-        if (e < np_all) Pb[e] = rp[t];
-        if (e < nx_all) xb[e] = rx[t];
-        if (e < nu_all) ub[e] = ru[t];
-    }
-    if (tid < nx) x0[size_t(b) * nx + tid] = x0_new[size_t(b) * nx + tid];
 }
 
 }  // namespace sddp

@@ -31,23 +31,40 @@ __host__ __device__ constexpr int pad2mod4(int n) { return ((n + 1) & ~3) + 2; }
 __host__ __device__ constexpr int round_up(int n, int m) { return (n + m - 1) / m * m; }
 __host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 
+// Whether the sweep of model M runs WITHOUT the dense (Vxx F)^T tile ("W-free"): models whose tiles would
+// not fit a CU's 160 KB with it (srbd61), or every model in a -DSDDP_WFREE_ALL diagnostic build.
+template <class M>
+constexpr bool mw_wfree() {
+#ifdef SDDP_WFREE_ALL
+    return true;
+#else
+    return M::NX > 40;
+#endif
+}
+
 template <class M>
 struct LdsMW {
     static constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NEV = M::NEV;
+    static constexpr bool WFREE = mw_wfree<M>();
     // register-block shapes: W = (V~F~)^T in JW x LW blocks, Q in 3x3 lower-triangle blocks, Vxx in 2x2 lower-triangle blocks
     static constexpr int JW = 3;
     static constexpr int LW = (round_up(NZ, 3) / 3) * (round_up(NX, 3) / 3) <= kThreadsMW ? 3 : 4;
     static constexpr int NJB = round_up(NZ, JW) / JW, NLB = round_up(NX, LW) / LW;
     static constexpr int NBQ = round_up(NZ, 3) / 3, NTRIQ = NBQ * (NBQ + 1) / 2;
     static constexpr int NBV = round_up(NX, 2) / 2, NTRIV = NBV * (NBV + 1) / 2;
+    static constexpr int TQ = (NTRIQ + kThreadsMW - 1) / kThreadsMW;            // Q blocks per thread (1: srbd37, lip30; 3: srbd61)
+    static constexpr int TV = (NTRIV + kThreadsMW - 1) / kThreadsMW;            // Vxx blocks per thread
     // row strides (doubles), all == 2 (mod 4); row counts padded to the block shapes (pad rows stay zero)
-    static constexpr int SV = pad2mod4(NX), RV = round_up(NX, imax(LW, 2));     // VXX [RV][SV]
+    static constexpr int SV = pad2mod4(NX), RV = round_up(NX, imax(WFREE ? 2 : LW, 2));     // VXX [RV][SV]
     static constexpr int RZ = round_up(NZ, 3);                                  // WT [RZ][SV], FC / WC [RZ][SC]
     static constexpr int ND = M::ND, SC = pad2mod4(ND + NEV);                   // compact columns: dense rows of F | variable extra rows
+    static constexpr int DG8 = (ND + 1) & ~1, SGC = pad2mod4(imax(ND, 1));      // W-free: GC [RZ][SGC], product depth DG8 (pad: zero)
     static constexpr int TBL = round_up(RZ, 2);                                 // per-column tables (pad rows: zero)
     static constexpr int SQ = pad2mod4(NZ);                                     // QU [NU][SQ]; the diagonal tables [SQ]
     static constexpr int SK = pad2mod4(NU);                                     // KT [NX][SK]: KT[c][i] = K[i][c]
     static constexpr int RPW = (NU + kWavesMW - 1) / kWavesMW;                  // Gauss-Jordan rows per wave
+    static constexpr int NCOL = NU + 1 + NX, CPL = (NCOL + kWave - 1) / kWave;  // augmented columns [Quu | Qu | Qux], columns per lane
+    static constexpr int GTS = CPL * kWave;                                     // hand-off row stride
     static constexpr int NSTG = M::NREC + M::NP + NX;                           // staged knot: record | params | defect
     static constexpr int NRECP = (((M::NREC + 1) & ~1) + M::NSO2T + 1) & ~1, NPP = (M::NP + 1) & ~1;   // record + second-order factors (SO2)
     static constexpr int SO2T = (M::NREC + 1) & ~1;
@@ -74,6 +91,11 @@ struct LdsMW {
     // its one neighbour entry (M::nbr); WT = (Vxx F)^T dense over the NX next-state columns, WC the same compact columns of
     // (V~ F~)^T (dense-row columns of WT duplicated | lambda_m E[m][z]).  The products run over the compact index (depth
     // ND + NEV instead of NX + NEV) plus two single terms per row.
+    // W-free layout (WFREE): no WT at all.  With column z of F = s_z + f_z (s_z: the identity and neighbour entries, f_z: the dense-row
+    // part), Q[z][z'] = s_z^T V s_z' + sum_d FC[z'][d] GC[z][d] + sum_c FC[z][c] WC[z'][c], where GC[z][d] = (V s_z)[D_d] is a compact
+    // RZ x ND tile, WC's dense-row columns are GC + (V f_z)[D_d] -- a depth-ND product with the ND x ND block of V -- and the first
+    // term is four gathers of V per element.  The gain tile and the hand-off rows then share the region of GC | WC, which are
+    // dead between the Q products and the next knot.
     static constexpr int VXX = WORK;
     static constexpr int FC = VXX + RV * SV;
     static constexpr int VX = FC + RZ * SC;
@@ -83,12 +105,13 @@ struct LdsMW {
     static constexpr int PK = REC + NRECP;
     static constexpr int DK = PK + NPP;                 // [SV], pad zero
     static constexpr int KF = DK + SV;                  // kff [SK]
-    static constexpr int WT = KF + SK;
-    // the gain tile and the Gauss-Jordan hand-off rows live where WT is dead (after the Q phase, until the next knot's W phase)
+    static constexpr int WT = KF + SK;                  // (W-free: the start of the shared region)
+    // the gain tile and the Gauss-Jordan hand-off rows live where WT (W-free: GC | WC) is dead: after the Q phase, until the next knot
     static constexpr int KT = WT;                       // KT [NX][SK]: KT[c][i] = K[i][c]
-    static constexpr int GT = KT + ((NX * SK + 1) & ~1);   // hand-off rows, double buffered [2][RPW][64]
-    static constexpr int WC = imax(WT + RZ * SV, GT + 2 * RPW * kWave);      // (small models: the tile is sized by what it hosts)
-    static constexpr int QU = WC + RZ * SC;             // [NU][SQ]: row i = row NX + i of Q (columns: state | input)
+    static constexpr int GT = KT + ((NX * SK + 1) & ~1);   // hand-off rows, double buffered [2][RPW][GTS]
+    static constexpr int GC = WT;                                                              // W-free only
+    static constexpr int WC = WFREE ? GC + RZ * SGC : imax(WT + RZ * SV, GT + 2 * RPW * GTS);  // (small models: the tile is sized by what it hosts)
+    static constexpr int QU = WFREE ? imax(WC + RZ * SC, GT + 2 * RPW * GTS) : WC + RZ * SC;   // [NU][SQ]: row i = row NX + i of Q (columns: state | input)
     static constexpr int SWEEP_END = QU + NU * SQ;
     // forward pass: per-lane vector columns X | U and the staged gains of one knot
     static constexpr int RO_X = WORK, RO_U = RO_X + NX * kWave, RO_G = RO_U + NU * kWave;
@@ -100,7 +123,9 @@ struct LdsMW {
     static constexpr int RO_END = RO_S + 2 * SB_N;
     static constexpr int TOTAL = imax(SWEEP_END, RO_END);
     static constexpr size_t BYTES = size_t(TOTAL) * sizeof(double);
-    static_assert((FC | VX | VP | QV | REC | PK | DK | KT | KF | GT | DS | DG | LS | LG | CTL | BET | IDC | KI | WORK | WT | WC | QU | RO_G) % 2 == 0, "16-byte aligned sections");
+    static_assert((FC | VX | VP | QV | REC | PK | DK | KT | KF | GT | GC | DS | DG | LS | LG | CTL | BET | IDC | KI | WORK | WT | WC | QU | RO_G) % 2 == 0, "16-byte aligned sections");
+    static_assert(BYTES <= size_t(160) * 1024, "the tiles of one instance must fit a CU's LDS");
+    static_assert(NU < kWave, "the pivot columns and the Qu column sit in the first column of every lane");
 };
 
 // C[i][j] += sum_m A[i][m] B[j][m], m < DEPTH (even): RA x RB register block, rows read two fp64 at a time (ds_read_b128).
@@ -212,21 +237,25 @@ __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
 }
 
 // The constant extra rows (m >= NEV: node-independent weights) contribute sum_m lambda_m E[m][row] E[m][col] to Q: a constant
-// matrix.  Each thread keeps the 3x3 block it owns in the Q phase in registers for the whole kernel.
+// matrix.  Each thread keeps the 3x3 blocks it owns in the Q phase (LdsMW::TQ of them) in registers for the whole kernel.
 template <class M>
-__device__ void mw_const_block(const DevConsts& c, int tid, double (&qconst)[3][3]) {
+__device__ void mw_const_block(const DevConsts& c, int tid, double (&qconst)[LdsMW<M>::TQ][3][3]) {
     using L = LdsMW<M>;
-    const int code = tid < L::NTRIQ ? tri_code(tid) : 0;
-    const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int tq = 0; tq < L::TQ; ++tq) {
+        const int t = tid + tq * kThreadsMW;
+        const int code = t < L::NTRIQ ? tri_code(t) : 0;
+        const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double v = 0.0;
-            if (M::NEV < M::NE && tid < L::NTRIQ && a0 + i < M::NZ && b0 + j < M::NZ)
-                for (int m = M::NEV; m < M::NE; ++m) v += M::lam_stage(c, m) * M::E_const(c, m, a0 + i) * M::E_const(c, m, b0 + j);
-            qconst[i][j] = v;
-        }
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double v = 0.0;
+                if (M::NEV < M::NE && t < L::NTRIQ && a0 + i < M::NZ && b0 + j < M::NZ)
+                    for (int m = M::NEV; m < M::NE; ++m) v += M::lam_stage(c, m) * M::E_const(c, m, a0 + i) * M::E_const(c, m, b0 + j);
+                qconst[tq][i][j] = v;
+            }
+    }
 }
 
 // backward Riccati sweep on 4 waves; every thread gets the same return value and the same dV1 / G1 / G2 / qu_inf.
@@ -234,16 +263,17 @@ template <class M>
 __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __restrict__ P, const double* __restrict__ dft,
                                   const double* __restrict__ rec, double* __restrict__ gains, double mu, double theta,
                                   double* s, int tid, double& dV1, double& G1, double& G2, double& qu_inf,
-                                  const double (&qconst)[3][3] SDDP_T_ARG) {
-    // qconst: the constant extra rows' share of this thread's 3x3 Q block (mw_const_block, once per kernel)
+                                  const double (&qconst)[LdsMW<M>::TQ][3][3] SDDP_T_ARG) {
+    // qconst: the constant extra rows' share of this thread's 3x3 Q blocks (mw_const_block, once per kernel)
     using L = LdsMW<M>;
     constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NE = M::NE, NEV = M::NEV, NREC = M::NREC, NP = M::NP;
     static_assert(!M::CONST_ROWS_STATE_WEIGHTED, "constant rows must have node-independent weights");
     constexpr int SV = L::SV, SC = L::SC, ND = L::ND, SQ = L::SQ, SK = L::SK, NSTG = L::NSTG, RPW = L::RPW;
-    constexpr int NCOL = NU + 1 + NX;
+    constexpr int NCOL = L::NCOL, CPL = L::CPL, GTS = L::GTS, TQ = L::TQ, TV = L::TV;
+    constexpr bool WFREE = L::WFREE;
     constexpr int RS = (NSTG + kThreadsMW - 1) / kThreadsMW;
     constexpr int kLast = kWavesMW - 1;
-    static_assert(NCOL <= kWave, "one lane per augmented column");
+    static_assert(NX <= kWave, "one lane per state in the v' and Vx phases");
     const int lane = tid & (kWave - 1), wave = tid / kWave;
     const int* ki = reinterpret_cast<const int*>(s + L::KI);
     const QSplit<NX> qm{s + L::VXX, SV, s + L::QU, SQ, s + L::DUMP};   // Q as the model code addresses it (LdsMW)
@@ -266,29 +296,33 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         if (a == b) v += s[L::DS + a] + M::dparam(c, s + L::PK, ki[a], ki[SQ + a], 1.0, 0.0);
         s[L::VXX + a * SV + b] = v;
     }
-    // the block this thread owns in the Q / Vxx phases never changes: decoded once per sweep
-    const int code_q = tid < L::NTRIQ ? tri_code(tid) : 0;
-    const int code_v = tid < L::NTRIV ? tri_code(tid) : 0;
-    // where the 3x3 block of Q goes (LdsMW: state rows inside the Vxx tile, input rows in QU, (state row, input column) nowhere):
-    // row offsets and one validity bit per element, for the block itself (d) and for its mirror image (m), once per sweep
-    int q_off_d[3], q_off_m[3];
-    unsigned q_ok_d = 0, q_ok_m = 0;
-    {
-        const int a0 = 3 * (code_q >> 8), b0 = 3 * (code_q & 255);
+    // the blocks this thread owns in the Q / Vxx phases never change: decoded once per sweep
+    int code_q[TQ], code_v[TV];
+#pragma unroll
+    for (int tq = 0; tq < TQ; ++tq) code_q[tq] = tid + tq * kThreadsMW < L::NTRIQ ? tri_code(tid + tq * kThreadsMW) : 0;
+#pragma unroll
+    for (int tv = 0; tv < TV; ++tv) code_v[tv] = tid + tv * kThreadsMW < L::NTRIV ? tri_code(tid + tv * kThreadsMW) : 0;
+    // where a 3x3 block of Q goes (LdsMW: state rows inside the Vxx tile, input rows in QU, (state row, input column) nowhere):
+    // row offsets and one validity bit per element, for the block itself (d) and for its mirror image (m)
+    auto q_place = [&](int code, int (&off_d)[3], int (&off_m)[3], unsigned& ok_d, unsigned& ok_m) {
+        const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
+        ok_d = ok_m = 0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int rd = a0 + i, rm = b0 + i;
-            q_off_d[i] = (rd >= NX ? L::QU + (rd - NX) * SQ : L::VXX + rd * SV) + b0;
-            q_off_m[i] = (rm >= NX ? L::QU + (rm - NX) * SQ : L::VXX + rm * SV) + a0;
+            off_d[i] = (rd >= NX ? L::QU + (rd - NX) * SQ : L::VXX + rd * SV) + b0;
+            off_m[i] = (rm >= NX ? L::QU + (rm - NX) * SQ : L::VXX + rm * SV) + a0;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int cd = b0 + j, cm = a0 + j;
-                if (rd < NZ && cd < NZ && (rd >= NX || cd < NX)) q_ok_d |= 1u << (3 * i + j);               // element (a0+i, b0+j)
-                if (a0 != b0 && rm < NZ && cm < NZ && (rm >= NX || cm < NX)) q_ok_m |= 1u << (3 * i + j);   // element (b0+i, a0+j)
+                if (rd < NZ && cd < NZ && (rd >= NX || cd < NX)) ok_d |= 1u << (3 * i + j);               // element (a0+i, b0+j)
+                if (a0 != b0 && rm < NZ && cm < NZ && (rm >= NX || cm < NX)) ok_m |= 1u << (3 * i + j);   // element (b0+i, a0+j)
             }
         }
-    }
-    static_assert(L::NTRIQ <= kThreadsMW && L::NTRIV <= kThreadsMW, "one block per thread");
+    };
+    int q_off_d[3], q_off_m[3];      // one block per thread (TQ == 1): placed once per sweep; else per trip
+    unsigned q_ok_d = 0, q_ok_m = 0;
+    if (TQ == 1) q_place(code_q[0], q_off_d, q_off_m, q_ok_d, q_ok_m);
     double r_stage[RS];
 #pragma unroll
     for (int t = 0; t < RS; ++t) r_stage[t] = stage_word(N - 1, tid + t * kThreadsMW);
@@ -342,6 +376,9 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         }
         __syncthreads();
         SDDP_TICK(2)
+        double qacc[TQ][3][3];       // the Q blocks of this thread (W-free: their s_z^T V s_z' part is formed BEFORE the barrier below,
+                                     // while V is still intact; the products and the stores -- Qxx goes into the V tile -- come after it)
+        if constexpr (!WFREE) {
         // ---- WT = (Vxx F)^T, JW x LW register blocks: row z = idc(z) Vxx[z] + beta(z) Vxx[n(z)] + sum_d F[D_d][z] Vxx[D_d] (the
         // column sparsity of F, M::nbr); the columns that are dense rows of F also go into the compact tile WC
         for (int blk = tid; blk < L::NJB * L::NLB; blk += kThreadsMW) {
@@ -396,19 +433,82 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 }
             }
         }
-        for (int e = tid; e < NZ * NEV; e += kThreadsMW) {    // extra rows: a scaling of F~^T
-            const int j = e / NEV, m = e % NEV;
-            const double lam = state * s[L::LS + m] + s[L::LG + m];
-            s[L::WC + j * SC + ND + m] = lam * s[L::FC + j * SC + ND + m];
+        } else {
+        // ---- W-free: the compact tiles GC[z][d] = (V s_z)[D_d] = idc(z) V[z][D_d] + beta(z) V[n(z)][D_d] and
+        // WC[z][d] = GC[z][d] + sum_d' FC[z][d'] V[D_d'][D_d], one thread per column z (the ND x ND block of V: broadcast reads)
+        if constexpr (ND > 0) {
+            for (int z = tid; z < NZ; z += kThreadsMW) {
+                const int zc = z < NX ? z : 0, nb = ki[L::NBI + z];
+                const double idc = s[L::IDC + z], bet = s[L::BET + z];
+                double fc[L::DG8], g[ND], w[ND];
+                load_run<L::DG8>(s + L::FC + z * SC, fc);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const double va = s[L::VXX + zc * SV + M::dense_row(d)], vb = s[L::VXX + nb * SV + M::dense_row(d)];
+                    g[d] = fma(bet, vb, idc * va);
+                    w[d] = g[d];
+                }
+#pragma unroll
+                for (int dp = 0; dp < ND; ++dp) {
+                    double vrow[ND];
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) vrow[d] = s[L::VXX + M::dense_row(dp) * SV + M::dense_row(d)];
+                    pin_regs(vrow);
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) w[d] = fma(fc[dp], vrow[d], w[d]);
+                }
+#pragma unroll
+                for (int d = 0; d < L::SGC; ++d) s[L::GC + z * L::SGC + d] = d < ND ? g[d < ND ? d : 0] : 0.0;   // pad columns zero: the product runs over DG8
+#pragma unroll
+                for (int d = 0; d < ND; ++d) s[L::WC + z * SC + d] = w[d];
+            }
+        }
+        // ... and the s_z^T V s_z' part of this thread's Q blocks: four gathers of V per element
+#pragma unroll
+        for (int tq = 0; tq < TQ; ++tq) {
+            const int a0 = 3 * (code_q[tq] >> 8), b0 = 3 * (code_q[tq] & 255);
+            double ia[3], ba[3], ib[3], bb[3];
+            int za[3], na[3], zb[3], nb[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int z = a0 + i, y = b0 + i;
+                za[i] = z < NX ? z : 0; na[i] = ki[L::NBI + z]; ia[i] = s[L::IDC + z]; ba[i] = s[L::BET + z];
+                zb[i] = y < NX ? y : 0; nb[i] = ki[L::NBI + y]; ib[i] = s[L::IDC + y]; bb[i] = s[L::BET + y];
+            }
+            double v00[3][3], v01[3][3], v10[3][3], v11[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    v00[i][j] = s[L::VXX + za[i] * SV + zb[j]];
+                    v01[i][j] = s[L::VXX + za[i] * SV + nb[j]];
+                    v10[i][j] = s[L::VXX + na[i] * SV + zb[j]];
+                    v11[i][j] = s[L::VXX + na[i] * SV + nb[j]];
+                }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { pin_regs(v00[i]); pin_regs(v01[i]); pin_regs(v10[i]); pin_regs(v11[i]); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    qacc[tq][i][j] = fma(ia[i], fma(ib[j], v00[i][j], bb[j] * v01[i][j]), ba[i] * fma(ib[j], v10[i][j], bb[j] * v11[i][j]));
+        }
+        }
+        for (int e = tid; e < NZ * (SC - ND); e += kThreadsMW) {    // extra rows: a scaling of F~^T (pad columns of WC: zero)
+            const int j = e / (SC - ND), m = e % (SC - ND);
+            const double lam = m < NEV ? state * s[L::LS + m] + s[L::LG + m] : 0.0;
+            s[L::WC + j * SC + ND + m] = m < NEV ? lam * s[L::FC + j * SC + ND + m] : 0.0;
         }
         __syncthreads();
         SDDP_TICK(3)
         // ---- Q = diag(D) + F~^T (V~ F~): 3x3 lower-triangle blocks, mirrored ; q = g + F^T v'
-        if (tid < L::NTRIQ) {
-            const int code = code_q;
+#pragma unroll
+        for (int tq = 0; tq < TQ; ++tq) {
+        if (tid + tq * kThreadsMW < L::NTRIQ) {
+            const int code = code_q[tq];
             const int a0 = 3 * (code >> 8), b0 = 3 * (code & 255);
             double acc[3][3] = {};
-            {   // the two single terms of every row a0 + i against rows b0 + j of WT first (dead before the product's operand ring)
+            if constexpr (!WFREE) {   // the two single terms of every row a0 + i against rows b0 + j of WT first (dead before the product's operand ring)
                 double idc[3], bet[3], wa[3][3], wb[3][3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -424,13 +524,19 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) acc[i][j] = fma(bet[i], wb[i][j], idc[i] * wa[i][j]);
+            } else {                  // W-free: s_z^T V s_z' from before the barrier, then s_z^T V f_z' = sum_d GC[z][d] FC[z'][d]
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][j] = qacc[tq][i][j];
+                if constexpr (ND > 0) dot_block<3, 3, L::DG8>(s + L::GC + a0 * L::SGC, L::SGC, s + L::FC + b0 * SC, SC, acc);
             }
             dot_block<3, 3, SC>(s + L::FC + a0 * SC, SC, s + L::WC + b0 * SC, SC, acc);
             if (NEV < NE) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[i][j] += qconst[i][j];
+                    for (int j = 0; j < 3; ++j) acc[i][j] += qconst[tq][i][j];
             }
             if (a0 == b0) {   // diagonal block: add D, keep it exactly symmetric
 #pragma unroll
@@ -444,6 +550,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             }
             // state rows go into the Vxx tile (dead since the W phase; both triangles: the Vxx update reads whole 2x2 blocks),
             // input rows into QU (both triangles of Quu: the solve reads whole rows), (state row, input column) is not stored
+            if (TQ > 1) q_place(code, q_off_d, q_off_m, q_ok_d, q_ok_m);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -451,6 +558,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                     if ((q_ok_d >> (3 * i + j)) & 1u) s[q_off_d[i] + j] = acc[i][j];
                     if ((q_ok_m >> (3 * j + i)) & 1u) s[q_off_m[j] + i] = acc[i][j];      // (b0+j, a0+i)
                 }
+        }
         }
         SDDP_TICK(13)
         if (wave == kLast) {
@@ -478,27 +586,36 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             __syncthreads();
         }
         SDDP_TICK(4)
-        // ---- [k K] = -Quu^-1 [Qu Qux]: block Gauss-Jordan, lane j = column j of [Quu+mu I | Qu | Qux], wave w = rows w RPW ..
+        // ---- [k K] = -Quu^-1 [Qu Qux]: block Gauss-Jordan, column (lane + 64 cc) of [Quu+mu I | Qu | Qux] in slot cc of a lane, wave w = rows w RPW ..
         {
-            double a[RPW], qu_save[RPW];
-            // column of Q this lane reads (any valid one for lane NU, which takes q instead; lanes >= NCOL are zeroed): branch-free
-            const int qcol = lane < NU ? NX + lane : (lane > NU && lane < NCOL ? lane - NU - 1 : 0);
+            double a[RPW][CPL], qu_save[RPW];
+            // column of Q a slot reads (any valid one for the slot of column NU, which takes q instead; columns >= NCOL are zeroed): branch-free
+            int qcol[CPL];
+#pragma unroll
+            for (int cc = 0; cc < CPL; ++cc) {
+                const int col = lane + kWave * cc;
+                qcol[cc] = col < NU ? NX + col : (col > NU && col < NCOL ? col - NU - 1 : 0);
+            }
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int i = wave * RPW + r, ic = i < NU ? i : NU - 1;
-                double v = s[L::QU + ic * SQ + qcol];
                 const double qv = s[L::QV + NX + ic];
-                v = lane == NU ? qv : v;
-                v += (i == lane) ? mu : 0.0;
-                v = (i < NU && lane < NCOL) ? v : 0.0;
-                a[r] = v;
-                qu_save[r] = v;
-                qu_acc = fmax(qu_acc, fabs(v));          // only lane NU's value is used
+#pragma unroll
+                for (int cc = 0; cc < CPL; ++cc) {
+                    const int col = lane + kWave * cc;
+                    double v = s[L::QU + ic * SQ + qcol[cc]];
+                    v = col == NU ? qv : v;
+                    v += (i == col) ? mu : 0.0;
+                    v = (i < NU && col < NCOL) ? v : 0.0;
+                    a[r][cc] = v;
+                }
+                qu_save[r] = a[r][0];
+                qu_acc = fmax(qu_acc, fabs(a[r][0]));          // only lane NU's value is used
             }
             SDDP_TICK(16)
 #pragma unroll
             for (int blk = 0; blk < kWavesMW; ++blk) {
-                double* gt = s + L::GT + (blk & 1) * RPW * kWave;
+                double* gt = s + L::GT + (blk & 1) * RPW * GTS;
                 if (wave == blk) {
                     bool ok = true;
 #pragma unroll
@@ -507,15 +624,21 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                         if (p < NU) {
                             double pv[RPW];
 #pragma unroll
-                            for (int rr = 0; rr < RPW; ++rr) pv[rr] = readlane_d(a[rr], p);
+                            for (int rr = 0; rr < RPW; ++rr) pv[rr] = readlane_d(a[rr][0], p);
                             if (!(pv[r] > 0.0) || !(pv[r] < 1e300)) ok = false;
-                            const double t = a[r] * fast_rcp(pv[r]);
+                            const double ip = fast_rcp(pv[r]);
 #pragma unroll
-                            for (int rr = 0; rr < RPW; ++rr) a[rr] = (rr == r) ? t : fma(-pv[rr], t, a[rr]);
+                            for (int cc = 0; cc < CPL; ++cc) {
+                                const double t = a[r][cc] * ip;
+#pragma unroll
+                                for (int rr = 0; rr < RPW; ++rr) a[rr][cc] = (rr == r) ? t : fma(-pv[rr], t, a[rr][cc]);
+                            }
                         }
                     }
 #pragma unroll
-                    for (int r = 0; r < RPW; ++r) gt[r * kWave + lane] = a[r];
+                    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < CPL; ++cc) gt[r * GTS + lane + kWave * cc] = a[r][cc];
                     if (lane == 0) s[L::CTL + 14 + (blk & 1)] = ok ? 1.0 : 0.0;
                 }
                 SDDP_TICK(17)
@@ -523,19 +646,50 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 SDDP_TICK(18)
                 if (s[L::CTL + 14 + (blk & 1)] == 0.0) return false;
                 if (wave != blk) {
-                    double pv[RPW][RPW], tv[RPW];
+                    if constexpr (RPW * RPW <= 36) {
+                        double pv[RPW][RPW], tv[RPW][CPL];
 #pragma unroll
-                    for (int r = 0; r < RPW; ++r) tv[r] = gt[r * kWave + lane];       // in flight behind the broadcasts below
+                        for (int r = 0; r < RPW; ++r)
 #pragma unroll
-                    for (int rr = 0; rr < RPW; ++rr)
+                            for (int cc = 0; cc < CPL; ++cc) tv[r][cc] = gt[r * GTS + lane + kWave * cc];       // in flight behind the broadcasts below
 #pragma unroll
-                        for (int r = 0; r < RPW; ++r) pv[rr][r] = readlane_d(a[rr], min(blk * RPW + r, NU - 1));
-                    pin_regs(tv);
+                        for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-                    for (int r = 0; r < RPW; ++r) {
-                        if (blk * RPW + r < NU) {
+                            for (int r = 0; r < RPW; ++r) pv[rr][r] = readlane_d(a[rr][0], min(blk * RPW + r, NU - 1));
 #pragma unroll
-                            for (int rr = 0; rr < RPW; ++rr) a[rr] = fma(-pv[rr][r], tv[r], a[rr]);
+                        for (int r = 0; r < RPW; ++r) pin_regs(tv[r]);
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) {
+                            if (blk * RPW + r < NU) {
+#pragma unroll
+                                for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+                                    for (int cc = 0; cc < CPL; ++cc) a[rr][cc] = fma(-pv[rr][r], tv[r][cc], a[rr][cc]);
+                            }
+                        }
+                    } else {
+                        // many rows per wave: the multipliers of one published row at a time (RPW x RPW of them do not fit the
+                        // registers).  Row r of the reduced block is the unit vector in the block's own columns but for rounding,
+                        // so the multiplier a[rr] at lane p_r is still the original entry when row r is reached.
+                        double tv[2][CPL];
+#pragma unroll
+                        for (int cc = 0; cc < CPL; ++cc) tv[0][cc] = gt[lane + kWave * cc];
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) {
+                            if (r + 1 < RPW) {
+#pragma unroll
+                                for (int cc = 0; cc < CPL; ++cc) tv[(r + 1) & 1][cc] = gt[(r + 1) * GTS + lane + kWave * cc];
+                            }
+                            double pv[RPW];
+#pragma unroll
+                            for (int rr = 0; rr < RPW; ++rr) pv[rr] = readlane_d(a[rr][0], min(blk * RPW + r, NU - 1));
+                            pin_regs(tv[r & 1]);
+                            if (blk * RPW + r < NU) {
+#pragma unroll
+                                for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+                                    for (int cc = 0; cc < CPL; ++cc) a[rr][cc] = fma(-pv[rr], tv[r & 1][cc], a[rr][cc]);
+                            }
                         }
                     }
                 }
@@ -545,16 +699,20 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             double dv = 0.0;
             // also the gains to HBM/L2 straight from the registers: kff (NU) then K (NU x NX) row-major; row i of K is one
             // contiguous store of the NX column lanes
-            double* dst = lane == NU ? s + L::KF : s + L::KT + (lane - NU - 1) * SK;
-            double* gk = gains + size_t(k) * (NU * (NX + 1)) + (lane == NU ? 0 : NU + (lane - NU - 1));
-            const int gstride = lane == NU ? 1 : NX;
-            const bool pub = lane >= NU && lane < NCOL;
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int i = wave * RPW + r;
-                if (i < NU) {
-                    if (pub) { dst[i] = -a[r]; gk[i * gstride] = -a[r]; }
-                    dv += -a[r] * qu_save[r];
+            for (int cc = 0; cc < CPL; ++cc) {
+                const int col = lane + kWave * cc;
+                double* dst = col == NU ? s + L::KF : s + L::KT + (col - NU - 1) * SK;
+                double* gk = gains + size_t(k) * (NU * (NX + 1)) + (col == NU ? 0 : NU + (col - NU - 1));
+                const int gstride = col == NU ? 1 : NX;
+                const bool pub = col >= NU && col < NCOL;
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int i = wave * RPW + r;
+                    if (i < NU) {
+                        if (pub) { dst[i] = -a[r][cc]; gk[i * gstride] = -a[r][cc]; }
+                        if (cc == 0) dv += -a[r][0] * qu_save[r];
+                    }
                 }
             }
             dv_acc += dv;                                 // only lane NU's value is used
@@ -573,8 +731,10 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             for (int i = 0; i < NU; ++i) acc += qr[i] * kv[i];
             s[L::VX + lane] = acc;
         }
-        if (tid < L::NTRIV) {
-            const int code = code_v;
+#pragma unroll
+        for (int tv = 0; tv < TV; ++tv) {
+        if (tid + tv * kThreadsMW < L::NTRIV) {
+            const int code = code_v[tv];
             const int a0 = 2 * (code >> 8), c0 = 2 * (code & 255);
             const int a1 = a0 + 1 < NX ? a0 + 1 : a0, c1 = c0 + 1 < NX ? c0 + 1 : c0;    // odd NX: clamp, not stored
             double v00 = 0, v01 = 0, v10 = 0, v11 = 0;
@@ -589,7 +749,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 v11 = fma(qb, kd, v11);
             }
             v00 += s[L::VXX + a0 * SV + c0];         // Qxx sits in the tile it is about to become (in place: a thread reads only
-            v01 += s[L::VXX + a0 * SV + c1];         // the block it owns; the mirrored stores below go to blocks above the
+            v01 += s[L::VXX + a0 * SV + c1];         // the blocks it owns; the mirrored stores below go to blocks above the
             v10 += s[L::VXX + a1 * SV + c0];         // diagonal, which no thread reads here)
             v11 += s[L::VXX + a1 * SV + c1];
             if (a0 == c0) { const double off = 0.5 * (v01 + v10); v01 = v10 = off; }
@@ -604,6 +764,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 if (ha) s[L::VXX + c0 * SV + a0 + 1] = v10;
                 if (ha && hc) s[L::VXX + (c0 + 1) * SV + a0 + 1] = v11;
             }
+        }
         }
         __syncthreads();
         SDDP_TICK(6)
@@ -787,7 +948,7 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
     double J = 0.0, gap = 0.0;
     SDDP_T_DECL
     sweep_tables_mw<M>(A.c, s, tid);
-    double qconst[3][3];
+    double qconst[LdsMW<M>::TQ][3][3];
     mw_const_block<M>(A.c, tid, qconst);
     // ---- starting point (cost and defect norm computed by wave 0, shared through CTL)
     if (o.initial_rollout) {
@@ -1000,7 +1161,7 @@ __global__ __launch_bounds__(kThreadsMW) void backward_kernel_mw(SolveArgs A) {
     }
     __syncthreads();
     double dV1, G1, G2, qu_inf;
-    double qconst[3][3];
+    double qconst[LdsMW<M>::TQ][3][3];
     mw_const_block<M>(A.c, tid, qconst);
     const bool ok = backward_sweep_mw<M>(A.c, N, P, dft, rec, gains, A.mu, A.alpha, s, tid, dV1, G1, G2, qu_inf, qconst SDDP_T_PASS);
     if (tid == 0) {

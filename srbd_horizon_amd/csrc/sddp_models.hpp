@@ -256,8 +256,9 @@ struct QSplit {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// SRBD family.  CS=false, NC=2: srbd13 (metric model, contacts are parameters);  CS=true, NC=4: srbd37
-// (reference problem, contacts are states -- prb.py:32-68).
+// SRBD family.  CS=false, NC=2: srbd13 (metric model, contacts are parameters);  CS=true: contacts are states
+// (reference problem, prb.py:32-68) -- NC=4: srbd37 (contact_model = 2, the launch file's), NC=8: srbd61 (contact_model = 4,
+// the default in the code, prb.py:39-41).  Two legs (number_of_legs = 2), CM = NC / 2 contact points per foot.
 // ---------------------------------------------------------------------------------------------------------
 template <int NC_, bool CS_, bool BAR_ = false, bool SO2_ = false>
 struct SrbdModel {
@@ -269,8 +270,18 @@ struct SrbdModel {
     static constexpr int NX = CS ? 13 + 6 * NC : 13;
     static constexpr int NU = CS ? 6 * NC : 3 * NC;
     static constexpr int NZ = NX + NU;
-    static constexpr int NP = 19;
-    static_assert((CS && NC == 4) || (!CS && NC == 2), "parameter layout is fixed to np=19");
+    static constexpr int CM = NC / 2;      // contact points per foot (rosparam contact_model, prb.py:39)
+    // parameters in creation order (ddp.py:173-177): rdot_ref(3) w_ref(3) otg(1) (c_ref_i, cdot_switch_i) x NC, oref(4)
+    static constexpr int NP = CS ? 11 + 2 * NC : 19;
+    static_assert((CS && (NC == 4 || NC == 8)) || (!CS && NC == 2), "srbd37 / srbd61 / srbd13");
+    static_assert(!BAR_ || (CS ? 13 + 12 * NC : 13 + 3 * NC) <= 64, "the bound barrier's masks cover 64 entries of z");
+    // relative-velocity penalty pairs (prb.py:166-170): q-th pair = (first contact of the leg, its i-th other contact)
+    static constexpr int NRV = CS ? 2 * (CM - 1) : 0, CM1 = CM > 1 ? CM - 1 : 1;
+    __device__ __forceinline__ static constexpr int rv_a(int q) { return (q / CM1) * CM; }
+    __device__ __forceinline__ static constexpr int rv_b(int q) { return (q / CM1) * CM + 1 + q % CM1; }
+    // number of pairs contact i is part of; whether (i, j), i != j, is a pair
+    __device__ __forceinline__ static constexpr int rv_count(int i) { return i % CM == 0 ? CM - 1 : 1; }
+    __device__ __forceinline__ static constexpr bool rv_paired(int i, int j) { return i / CM == j / CM && (i % CM == 0 || j % CM == 0); }
     // state offsets (prb.py:32-59 creation order)
     static constexpr int XR = 0, XO = 3, XC = 7, XRD = CS ? 7 + 3 * NC : 7, XW = XRD + 3, XCD = XW + 3;
     // compact columns of A = d wdot / d z : r(0..2) o(3..6) w(7..9) [c(3NC)] f(3NC)
@@ -297,7 +308,7 @@ struct SrbdModel {
     __device__ __forceinline__ static double p_rdref(const double* p, int a) { return p[a]; }
     __device__ __forceinline__ static double p_wref(const double* p, int a) { return p[3 + a]; }
     __device__ __forceinline__ static double p_otg(const double* p) { return p[6]; }
-    __device__ __forceinline__ static double p_oref(const double* p, int a) { return CS ? p[15 + a] : p[7 + a]; }
+    __device__ __forceinline__ static double p_oref(const double* p, int a) { return CS ? p[7 + 2 * NC + a] : p[7 + a]; }
     __device__ __forceinline__ static double p_sw(const double* p, int i) { return CS ? p[8 + 2 * i] : p[17 + i]; }
     __device__ __forceinline__ static double p_cref(const double* p, int i) { return p[7 + 2 * i]; }
 
@@ -451,8 +462,9 @@ struct SrbdModel {
                 L += c.w_pen * (ez * ez + vx * vx + vy * vy);
             }
 #pragma unroll
-            for (int b = 0; b < NC; b += 2) {
-                const double ex = x[XCD + 3 * b] - x[XCD + 3 * b + 3], ey = x[XCD + 3 * b + 1] - x[XCD + 3 * b + 4];
+            for (int q = 0; q < NRV; ++q) {
+                const int a = rv_a(q), b = rv_b(q);
+                const double ex = x[XCD + 3 * a] - x[XCD + 3 * b], ey = x[XCD + 3 * a + 1] - x[XCD + 3 * b + 1];
                 L += c.w_pen * (ex * ex + ey * ey);
             }
         }
@@ -662,10 +674,11 @@ struct SrbdModel {
                     g[XCD + 3 * i + 1] += sp * sw * sw * x[XCD + 3 * i + 1];
                 }
 #pragma unroll
-                for (int b = 0; b < NC; b += 2) {
-                    const double ex = x[XCD + 3 * b] - x[XCD + 3 * b + 3], ey = x[XCD + 3 * b + 1] - x[XCD + 3 * b + 4];
-                    g[XCD + 3 * b] += sp * ex; g[XCD + 3 * b + 3] -= sp * ex;
-                    g[XCD + 3 * b + 1] += sp * ey; g[XCD + 3 * b + 4] -= sp * ey;
+                for (int q = 0; q < NRV; ++q) {
+                    const int a = rv_a(q), b = rv_b(q);
+                    const double ex = x[XCD + 3 * a] - x[XCD + 3 * b], ey = x[XCD + 3 * a + 1] - x[XCD + 3 * b + 1];
+                    g[XCD + 3 * a] += sp * ex; g[XCD + 3 * b] -= sp * ex;
+                    g[XCD + 3 * a + 1] += sp * ey; g[XCD + 3 * b + 1] -= sp * ey;
                 }
             }
             if (BAR) (void)bound_cost(c, x, u, g, rec + REC_BB);   // bound barrier (off: zeros): gradient into g, GN Hessian diagonal into the record
@@ -856,8 +869,8 @@ struct SrbdModel {
                     break;
                 case V_CD:
                     if (stage && ai < 2) {
-                        if (ci == cj) { const double sw = p_sw(p, ci); v = 2 * c.w_pen * (1.0 + sw * sw); }
-                        else if (ci / 2 == cj / 2) v = -2 * c.w_pen;
+                        if (ci == cj) { const double sw = p_sw(p, ci); v = 2 * c.w_pen * (double(rv_count(ci)) + sw * sw); }
+                        else if (rv_paired(ci, cj)) v = -2 * c.w_pen;
                     }
                     break;
                 case V_CDD: if (stage && ci == cj) v = 2 * c.gq; break;
@@ -887,7 +900,7 @@ struct SrbdModel {
     // augmented Jacobian F~ = [F ; Je] with its weight on the diagonal of V~ = blockdiag(Vxx+, Lambda), so that
     // Q = diag(D) + F~^T V~ F~ needs no special cases.  Only the wdot rows (A) and the quaternion blocks vary per knot.
     // -------------------------------------------------------------------------------------------------------------
-    static constexpr int NE = 6 + (CS ? 4 + NC : 0);   // wdot(3) rddot(3) [rel_pos(4) rel_vel(NC)]
+    static constexpr int NE = 6 + (CS ? 4 + 2 * NRV : 0);   // wdot(3) rddot(3) [rel_pos(4) rel_vel(2 per pair)]
     // Extra rows m >= NEV are constant (E_const) and their weights do not depend on the node: their contribution
     // sum_m lambda_m e_m e_m^T to Q is a constant matrix that the one-wave kernel adds instead of carrying the rows through the
     // tile products (srbd13: the three rddot rows -> product depth 20 -> 16).  NEV = NE: every row goes through the product.
@@ -920,7 +933,7 @@ struct SrbdModel {
         }
         const int pair = (m - 10) / 2, comp = (m - 10) % 2;                                 // relative_vel rows prb.py:166-170
         if (cls != V_CD || ax != comp) return 0.0;
-        return ci == 2 * pair ? 1.0 : (ci == 2 * pair + 1 ? -1.0 : 0.0);
+        return ci == rv_a(pair) ? 1.0 : (ci == rv_b(pair) ? -1.0 : 0.0);
     }
     __device__ static double lam_state(const DevConsts& c, int mrow) {
         const int m = erow(mrow);
@@ -967,7 +980,7 @@ struct SrbdModel {
         // every parameter read requested unconditionally and together (pinned): left alone the compiler sinks each read into the
         // select that consumes it and the selects become branches with an exposed LDS round trip each
         double otg = p_otg(p), o0 = p_oref(p, 0), o1 = p_oref(p, 1), o2 = p_oref(p, 2), o3 = p_oref(p, 3);
-        double sw = CS ? p[8 + 2 * ci] : p[17 + ci];
+        double sw = p_sw(p, ci);
         asm volatile("" : "+v"(otg), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(sw));
         const double n2 = o0 * o0 + o1 * o1 + o2 * o2 + o3 * o3;
         const double v1 = state * 2 * otg * otg * n2;
@@ -1511,6 +1524,7 @@ using Srbd13S = SrbdModel<2, false, false, true>;   // full second-order builds 
 using Srbd37S = SrbdModel<4, true, false, true>;
 using Srbd13BS = SrbdModel<2, false, true, true>;    // barrier + full second order
 using Srbd37BS = SrbdModel<4, true, true, true>;
+using Srbd61 = SrbdModel<8, true>;                  // contact_model = 4 (prb.py:39-41): default build only
 using Lip30 = LipModel;
 
 }  // namespace sddp

@@ -42,7 +42,9 @@ def _srbd_terms(nc, contact_states):
     if contact_states:
         for nm in ("rel_pos_y_1_4", "rel_pos_x_1_4", "rel_pos_y_3_6", "rel_pos_x_3_6"):
             cost[nm] = ("rel_pos_gain", "state")
-        eq = ["relative_vel_left_1", "relative_vel_right_3"] + [f"{t}{i}" for i in range(nc) for t in ("cz_tracking", "cdotxy_tracking")]
+        cm = nc // 2                                                           # prb.py:166-170
+        eq = [f"relative_vel_left_{i}" for i in range(1, cm)] + [f"relative_vel_right_{i}" for i in range(cm + 1, 2 * cm)] + \
+             [f"{t}{i}" for i in range(nc) for t in ("cz_tracking", "cdotxy_tracking")]
     for i in range(nc):
         cost[f"min_f{i}"] = ("min_f_gain", "stage")
         cost[f"f{i}_active"] = ("force_switch_weight", "stage")
@@ -51,6 +53,7 @@ def _srbd_terms(nc, contact_states):
 
 MODEL_TERMS = {
     "srbd37": _srbd_terms(4, True),
+    "srbd61": _srbd_terms(8, True),
     "srbd13": _srbd_terms(2, False),
     "lip30": dict(cost={"rz_tracking": ("r_tracking_gain", "state"), "rxy_tracking": ("r_tracking_gain", "state"),
                         "rdot_tracking": ("rdot_tracking_gain", "state"), "zmp_tracking": ("zmp_tracking_gain", "stage"),

@@ -248,6 +248,16 @@ class DdpEngine:
         self._chk(self.lib.sddp_queue_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def kernel_info(self):
+        """-> dict(kernel, wavefronts_per_instance, waves_per_simd): the solve kernel the LAST launch of this handle ran
+        (``solve_kernel[_w2]<model>`` on one wavefront per instance or ``solve_kernel_mw[_w2]<model>`` on four; ``_w2`` = the
+        half-register-file build, which a handle asked for two per SIMD falls back from where it gains nothing)."""
+        w, b, nm = C.c_int(), C.c_int(), C.c_char_p()
+        self._chk(self.lib.sddp_kernel_info(self.h, C.byref(w), C.byref(b), C.byref(nm)))
+        base = "solve_kernel_mw" if w.value == 4 else "solve_kernel"
+        return dict(kernel=f"{base}{'_w2' if b.value == 2 else ''}<{nm.value.decode()}>", wavefronts_per_instance=w.value,
+                    waves_per_simd=b.value)
+
 
 def eval_knots(model: str, N: int, k, x, u, p, consts: dict | None = None):
     """Per-knot model evaluation on the GPU: f, [fx fu], GN Hessian, gradient, cost (parity tests)."""

@@ -30,9 +30,9 @@ class MpcLoop:
         last parameter column and the state cross PCIe), "previous" = previous solution as is (what a stateful pyddp object
         would keep), "reset" = x0 repeated / static input."""
         T = ns * 0.05 if T is None else T                              # wpg hard-codes dt = 0.05 (wpg.py:20)
-        if model == "srbd37":
+        if model in ("srbd37", "srbd61"):
             self.srbd = SRBDProblem()
-            self.srbd.createSRBDProblem(ns, T, robot)
+            self.srbd.createSRBDProblem(ns, T, robot, params=dict(contact_model=2 if model == "srbd37" else 4))
             contact_model = self.srbd.contact_model
         elif model == "srbd13":
             self.srbd = SRBD13Problem()
@@ -134,7 +134,7 @@ class MpcLoop:
         taken from the solution at ``node`` (the reference publishes node 1, the next tick's target)."""
         o = sol["o"][:, node] if "o" in sol else np.array([0.0, 0.0, 0.0, 1.0])          # dlip_example.py:145 publishes identity
         rec = {"com": np.array(sol["r"][:, node]), "base_link": np.array(o), "contacts": {}}
-        if self.model in ("srbd37", "lip30"):
+        if self.model in ("srbd37", "srbd61", "lip30"):
             cm = self.srbd.contact_model
             for leg, frame in enumerate(foot_frames):
                 pts = [sol["c" + str(leg * cm + j)][:, node] for j in range(cm)]

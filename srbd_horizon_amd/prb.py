@@ -28,6 +28,10 @@ class RobotModel:
     # left_foot_upper, left_foot_lower, right_foot_upper, right_foot_lower (launch:24-25)
     feet: np.ndarray = field(default_factory=lambda: np.array(
         [[0.08, 0.1, 0.0], [-0.08, 0.1, 0.0], [0.08, -0.1, 0.0], [-0.08, -0.1, 0.0]]))
+    # contact_model = 4 (the default in the code, prb.py:39): the four corners of the left sole, then of the right one
+    feet8: np.ndarray = field(default_factory=lambda: np.array(
+        [[0.08, 0.13, 0.0], [-0.08, 0.13, 0.0], [0.08, 0.07, 0.0], [-0.08, 0.07, 0.0],
+         [0.08, -0.07, 0.0], [-0.08, -0.07, 0.0], [0.08, -0.13, 0.0], [-0.08, -0.13, 0.0]]))
 
 
 # rosparam names and defaults (prb.py:39-40, :142-150, :358-362)
@@ -97,7 +101,9 @@ def _declare_srbd_terms(prb, prm, ns, nc, contact_model, with_contact_states: bo
 
 
 class SRBDProblem:
-    """prb.py:16-246 -- nx = 37, nu = 24, np = 19 with the launch file's contact_model=2, number_of_legs=2."""
+    """prb.py:16-246 -- nx = 37, nu = 24, np = 19 with the launch file's contact_model=2, number_of_legs=2 (model "srbd37");
+    nx = 61, nu = 48, np = 27 with the defaults in the code, contact_model=4, number_of_legs=2 (prb.py:39-40; model "srbd61",
+    pass params={"contact_model": 4})."""
 
     def createSRBDProblem(self, ns, T, robot: RobotModel | None = None, params: dict | None = None):
         robot = robot or RobotModel()
@@ -105,8 +111,9 @@ class SRBDProblem:
         prb = Problem(ns)
         contact_model, number_of_legs = prm["contact_model"], prm["number_of_legs"]
         nc = number_of_legs * contact_model
-        if nc != 4 or contact_model != 2:
-            raise ValueError("the reference's SRBD problem indexes feet 0..3 (prb.py:153-154): contact_model=2, number_of_legs=2")
+        if number_of_legs != 2 or contact_model not in (2, 4):
+            raise ValueError("analytic models exist for number_of_legs=2 with contact_model=2 (srbd37, the launch file's) and "
+                             "contact_model=4 (srbd61, the default in prb.py:39); the problem indexes feet 0..3 (prb.py:153-154)")
         r = prb.createStateVariable("r", 3)                                   # prb.py:32
         o = prb.createStateVariable("o", 4)                                   # prb.py:33
         q = Aggregate(); q.addVariable(r); q.addVariable(o)
@@ -121,7 +128,7 @@ class SRBDProblem:
         rdot_ref = prb.createParameter("rdot_ref", 3)                         # prb.py:71
         w_ref = prb.createParameter("w_ref", 3)                               # prb.py:72
         prb.setDt(T / ns)                                                     # prb.py:110
-        feet = np.asarray(robot.feet, dtype=float)
+        feet = np.asarray(robot.feet if nc == 4 else robot.feet8, dtype=float)
         otg = prb.createParameter("orientation_tracking_gain", 1)             # prb.py:143
         otg.assign(1e1)                                                       # prb.py:144
         c_ref, cdot_switch = {}, {}
@@ -133,7 +140,8 @@ class SRBDProblem:
         oref = prb.createParameter("oref", 4)                                 # prb.py:185
         oref.assign(quat_inverse(np.array([0.0, 0.0, 0.0, 1.0])))             # prb.py:186
         _declare_srbd_terms(prb, prm, ns, nc, contact_model, True)            # prb.py:166-204
-        prb.setModel("srbd37", _consts(robot, prm, T / ns, feet))
+        # the graphs only use contact points 0..3 (d_initial_1 / d_initial_2, prb.py:153-154), whatever nc is
+        prb.setModel("srbd37" if nc == 4 else "srbd61", _consts(robot, prm, T / ns, feet[:4]))
         self.prb = prb
         self.initial_foot_position = {i: feet[i].copy() for i in range(nc)}
         self.com = np.asarray(robot.com, dtype=float)
@@ -149,9 +157,10 @@ class SRBDProblem:
         return np.concatenate([self.com, [0.0, 0.0, 0.0, 1.0]] + [self.initial_foot_position[i] for i in range(self.nc)]
                               + [np.zeros(6 + 3 * self.nc)])
 
-    def getStaticInput(self):                                                 # prb.py:242-246
-        fz = self.m * 9.81 / self.force_scaling / 4
-        return np.tile([0.0, 0.0, 0.0, 0.0, 0.0, fz], 4)
+    def getStaticInput(self):
+        # prb.py:242-246 writes four blocks with m g / force_scaling / 4 (its nc = 4): the weight shared by the nc contact points
+        fz = self.m * 9.81 / self.force_scaling / self.nc
+        return np.tile([0.0, 0.0, 0.0, 0.0, 0.0, fz], self.nc)
 
 
 class SRBD13Problem:

@@ -125,32 +125,35 @@ def schedule_by_ticking(N: int, seed: int, robot: RobotModel | None = None):
     return pb.prb.parameter_matrix()
 
 
-def make_srbd37_batch(N: int, seeds, robot: RobotModel | None = None):
-    """Reference-faithful SRBD (nc = 4 line feet, launch:16-17): the line-foot contact schedule of config 5."""
+def make_srbd37_batch(N: int, seeds, robot: RobotModel | None = None, contact_model: int = 2):
+    """Reference-faithful SRBD (nc = 4 line feet, launch:16-17): the line-foot contact schedule of config 5.
+    contact_model = 4: the same schedule on the problem's code-default nc = 8 (srbd61, prb.py:39-41)."""
     robot = robot or RobotModel()
     seeds = np.asarray(seeds, dtype=np.int64)
     B = seeds.shape[0]
+    nc = 2 * contact_model
     pb = SRBDProblem()
-    pb.createSRBDProblem(N, N * 0.05, robot)
+    pb.createSRBDProblem(N, N * 0.05, robot, params=dict(contact_model=contact_model))
     z, sw, otg, _ = _closed_form(N, seeds, 0.0, 1.0, 1e1)
     a = np.stack([np.random.default_rng(int(s)).integers(-1, 2, size=2) for s in seeds]).astype(float)
-    P = np.zeros((B, N + 1, 19))
+    P = np.zeros((B, N + 1, 11 + 2 * nc))
     P[:, :, 0:2] = 0.5 * a[:, None, :]
     P[:, :, 6] = otg
-    for i in range(4):
-        leg = 0 if i < 2 else 1
+    for i in range(nc):
+        leg = 0 if i < contact_model else 1                   # wpg.py:84: contacts i < contact_model belong to the left foot
         P[:, :, 7 + 2 * i] = z[:, leg, :]
         P[:, :, 8 + 2 * i] = sw[:, leg, :]
-    P[:, :, 15:19] = np.array([-0.0, -0.0, -0.0, 1.0])
+    P[:, :, 7 + 2 * nc:11 + 2 * nc] = np.array([-0.0, -0.0, -0.0, 1.0])
     x0 = np.tile(pb.getInitialState(), (B, 1))
+    rd0 = 7 + 3 * nc
     for b, s in enumerate(seeds):
         rng = np.random.default_rng(int(s) + 1_000_003)
         x0[b, 0:3] += 0.01 * rng.standard_normal(3)
         dq = 0.02 * rng.standard_normal(3)
         q = np.array([dq[0], dq[1], dq[2], 1.0])
         x0[b, 3:7] = q / np.linalg.norm(q)
-        x0[b, 19:22] += 0.05 * rng.standard_normal(3)
-        x0[b, 22:25] += 0.05 * rng.standard_normal(3)
+        x0[b, rd0:rd0 + 3] += 0.05 * rng.standard_normal(3)
+        x0[b, rd0 + 3:rd0 + 6] += 0.05 * rng.standard_normal(3)
     xs = np.repeat(x0[:, None, :], N + 1, axis=1)
     us = np.tile(pb.getStaticInput(), (B, N, 1))
     return dict(x0=x0, params=P, xs=xs, us=us, consts=pb.prb.model_consts, problem=pb)
@@ -180,7 +183,11 @@ def make_lip30_batch(N: int, seeds, robot: RobotModel | None = None):
     return dict(x0=x0, params=P, xs=xs, us=us, consts=pb.prb.model_consts, problem=pb)
 
 
-MAKERS = {"srbd13": make_srbd13_batch, "srbd37": make_srbd37_batch, "lip30": make_lip30_batch}
+def make_srbd61_batch(N: int, seeds, robot: RobotModel | None = None):
+    return make_srbd37_batch(N, seeds, robot, contact_model=4)
+
+
+MAKERS = {"srbd13": make_srbd13_batch, "srbd37": make_srbd37_batch, "lip30": make_lip30_batch, "srbd61": make_srbd61_batch}
 
 
 def make_batch(model: str, N: int, seeds, robot: RobotModel | None = None):

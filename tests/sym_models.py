@@ -57,16 +57,23 @@ def _force_res(cst, f, sw):
 
 
 def _penalties(cs, cds, cref, sw):
+    """prb.py:166-170 (relative velocities inside a foot: contact_model = nc / 2 points per foot) and :179-181"""
     g = sp.sqrt(1e6)
-    out = [*(g * (cds[0][0:2, 0] - cds[1][0:2, 0])), *(g * (cds[2][0:2, 0] - cds[3][0:2, 0]))]
-    for i in range(4):
+    nc = len(cs)
+    cm = nc // 2
+    out = []
+    for i in range(1, cm):
+        out += [*(g * (cds[0][0:2, 0] - cds[i][0:2, 0]))]
+    for i in range(cm + 1, 2 * cm):
+        out += [*(g * (cds[cm][0:2, 0] - cds[i][0:2, 0]))]
+    for i in range(nc):
         out.append(g * (cs[i][2] - cref[i]))
         out += [g * sw[i] * cds[i][0], g * sw[i] * cds[i][1]]
     return out
 
 
 def _relpos(cst, cs):
-    feet = np.asarray(cst.feet)
+    feet = np.asarray(cst.feet if len(cs) == 4 else cst.feet8)
     d1 = feet[2][0:2] - feet[0][0:2]
     d2 = feet[3][0:2] - feet[1][0:2]
     g = sp.sqrt(cst.rel_pos_gain)
@@ -79,6 +86,8 @@ def _build(name, cst):
         nx, nu, npar = 13, 6, 19
     elif name == "srbd37":
         nx, nu, npar = 37, 24, 19
+    elif name == "srbd61":
+        nx, nu, npar = 61, 48, 27
     else:
         nx, nu, npar = 30, 15, 11
     x = sp.Matrix(sp.symbols(f"x0:{nx}"))
@@ -95,20 +104,22 @@ def _build(name, cst):
         ires = [*(sp.sqrt(cst.min_qddot_gain) * sp.Matrix([*rddot, *wdot]))]
         for i in range(2):
             ires += _force_res(cst, fs[i], p[17 + i])
-    elif name == "srbd37":
-        r, o, rd, w = x[0:3, 0], x[3:7, 0], x[19:22, 0], x[22:25, 0]
-        cs = [x[7 + 3 * i:10 + 3 * i, 0] for i in range(4)]
-        cds = [x[25 + 3 * i:28 + 3 * i, 0] for i in range(4)]
-        cdd = [u[6 * i:6 * i + 3, 0] for i in range(4)]
-        fs = [u[6 * i + 3:6 * i + 6, 0] for i in range(4)]
+    elif name in ("srbd37", "srbd61"):
+        # x = r | o | c_i | rdot | w | cdot_i ; u = (cddot_i, f_i) interleaved ; p = rdot_ref | w_ref | otg | (c_ref_i, sw_i) | oref
+        nc = 4 if name == "srbd37" else 8
+        rd0 = 7 + 3 * nc
+        r, o, rd, w = x[0:3, 0], x[3:7, 0], x[rd0:rd0 + 3, 0], x[rd0 + 3:rd0 + 6, 0]
+        cs = [x[7 + 3 * i:10 + 3 * i, 0] for i in range(nc)]
+        cds = [x[rd0 + 6 + 3 * i:rd0 + 9 + 3 * i, 0] for i in range(nc)]
+        cdd = [u[6 * i:6 * i + 3, 0] for i in range(nc)]
+        fs = [u[6 * i + 3:6 * i + 6, 0] for i in range(nc)]
         rddot, wdot, odot = _srbd(cst, r, o, w, cs, fs)
-        xdot = sp.Matrix([*rd, *odot, *cds[0], *cds[1], *cds[2], *cds[3], *rddot, *wdot,
-                          *cdd[0], *cdd[1], *cdd[2], *cdd[3]])
-        sres = _state_res(cst, r, o, rd, w, p[0:3, 0], p[3:6, 0], p[6], p[15:19, 0]) + _relpos(cst, cs)
-        ires = [*(sp.sqrt(cst.min_qddot_gain) * sp.Matrix([*rddot, *wdot, *cdd[0], *cdd[1], *cdd[2], *cdd[3]]))]
-        for i in range(4):
+        xdot = sp.Matrix([*rd, *odot, *[e for c in cds for e in c], *rddot, *wdot, *[e for c in cdd for e in c]])
+        sres = _state_res(cst, r, o, rd, w, p[0:3, 0], p[3:6, 0], p[6], p[7 + 2 * nc:11 + 2 * nc, 0]) + _relpos(cst, cs)
+        ires = [*(sp.sqrt(cst.min_qddot_gain) * sp.Matrix([*rddot, *wdot, *[e for c in cdd for e in c]]))]
+        for i in range(nc):
             ires += _force_res(cst, fs[i], p[8 + 2 * i])
-        ires += _penalties(cs, cds, [p[7 + 2 * i] for i in range(4)], [p[8 + 2 * i] for i in range(4)])
+        ires += _penalties(cs, cds, [p[7 + 2 * i] for i in range(nc)], [p[8 + 2 * i] for i in range(nc)])
     else:
         r, rd = x[0:3, 0], x[15:18, 0]
         cs = [x[3 + 3 * i:6 + 3 * i, 0] for i in range(4)]

@@ -26,16 +26,27 @@ def test_header_symbols_are_all_bound_and_exported(lib):
 
 
 def test_struct_layouts_and_dims(lib):
-    assert lib.sddp_abi_version() == 7
+    assert lib.sddp_abi_version() == 8
     assert _lib.model_dims("srbd13") == (13, 6, 19)
     assert _lib.model_dims("srbd37") == (37, 24, 19)
     assert _lib.model_dims("lip30") == (30, 15, 11)
+    assert _lib.model_dims("srbd61") == (61, 48, 27)                      # contact_model = 4, prb.py:39-41
+    assert lib.sddp_model_dims(4, None, None, None) != 0
     o = _lib.default_options()
     # Python-side defaults of the reference adapter (ddp.py:17-29)
     assert (o.max_iters, o.alpha_0, o.alpha_converge_threshold, o.line_search_decrease_factor, o.beta) == (100, 1.0, 1e-1, 0.5, 1e-4)
     c = _lib.default_consts()
     assert c.force_scaling == 1000.0 and c.dt == 0.05 and c.inertia_mode == 0 and abs(c.com[2] - 0.88) < 1e-15
     assert C.sizeof(_lib.SddpStats) == 56
+
+
+def test_set_consts_resets_the_tail_of_the_bounds():
+    """a reused constants struct keeps no stale bound beyond the values given"""
+    import numpy as np
+    c = _lib.default_consts(lower=[-1.0] * 19, upper=[1.0] * 19)
+    assert c.lower[18] == -1.0 and c.upper[18] == 1.0
+    _lib.set_consts(c, lower=[-2.0] * 13, upper=[2.0] * 13)
+    assert c.lower[12] == -2.0 and c.lower[13] == -np.inf and c.upper[18] == np.inf
 
 
 def test_no_cpu_fallback_without_device(lib):

@@ -21,6 +21,7 @@ def test_two_instances_of_the_reference_problem_fit_one_cu(tmp_path):
     assert rows["srbd37"][0] <= 64 * 1024 and 2 * rows["srbd37"][0] <= cu          # 63.8 KB: two workgroups per CU
     assert 2 * rows["srbd37S"][0] <= cu and 2 * rows["srbd37B"][0] <= cu            # second-order and barrier builds too
     assert 2 * rows["lip30"][0] <= cu
+    assert rows["srbd61"][0] <= 146 * 1024                                          # contact_model = 4 (W-free layout): one workgroup per CU
     assert 8 * rows["srbd13"][0] <= cu                                              # one-wave kernel: eight wavefronts per CU
     for name, (nbytes, work, two) in rows.items():
         assert nbytes <= cu, name

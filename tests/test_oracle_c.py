@@ -72,7 +72,7 @@ def test_exhausted_line_search_is_a_stall_not_convergence_in_both_oracles():
     assert r3.status == 4 and not r3.converged and int(st3[0, 6]) == 4 and int(st3[0, 2]) == 0
 
 
-@pytest.mark.parametrize("name,barrier", [("srbd37", 0.0), ("srbd37", 6.0), ("lip30", 0.0)])
+@pytest.mark.parametrize("name,barrier", [("srbd37", 0.0), ("srbd37", 6.0), ("lip30", 0.0), ("srbd61", 0.0), ("srbd61", 6.0)])
 def test_c_knot_evaluation_matches_numpy_reference_models(name, barrier):
     cst = omodels.RobotConsts(friction_barrier_weight=barrier, friction_barrier_sharpness=4.0)
     m = omodels.make_model(name, cst)
@@ -96,7 +96,7 @@ def test_c_knot_evaluation_matches_numpy_reference_models(name, barrier):
             np.testing.assert_allclose(H, np.block([[lxx, lux.T], [lux, luu]]), rtol=1e-11, atol=1e-9 * np.max(np.abs(H)))
 
 
-@pytest.mark.parametrize("name,N,seeds", [("srbd37", 20, [0, 3]), ("lip30", 20, [1, 2]), ("srbd37", 8, [5])])
+@pytest.mark.parametrize("name,N,seeds", [("srbd37", 20, [0, 3]), ("lip30", 20, [1, 2]), ("srbd37", 8, [5]), ("srbd61", 20, [0, 2]), ("srbd61", 6, [7])])
 def test_c_solve_matches_numpy_solve_reference_models(name, N, seeds):
     batch = workload.make_batch(name, N, seeds)
     cst = omodels.RobotConsts()
@@ -110,7 +110,7 @@ def test_c_solve_matches_numpy_solve_reference_models(name, N, seeds):
         assert abs(st[b, 0] - r.cost) <= 1e-9 * abs(r.cost)
 
 
-@pytest.mark.parametrize("name,N,seeds,bar", [("srbd13", 30, [1, 2, 4], 0.0), ("srbd37", 12, [3], 0.0), ("srbd13", 30, [2], 2.0)])
+@pytest.mark.parametrize("name,N,seeds,bar", [("srbd13", 30, [1, 2, 4], 0.0), ("srbd37", 12, [3], 0.0), ("srbd13", 30, [2], 2.0), ("srbd61", 10, [4], 0.0)])
 def test_c_full_second_order_solve_matches_numpy(name, N, seeds, bar):
     """second_order = 2 (v'.f_zz + exact cost Hessian after full steps): the C port takes the same path as the numpy oracle."""
     batch = workload.make_batch(name, N, seeds)

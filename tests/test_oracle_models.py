@@ -16,7 +16,7 @@ def _rand_point(m, rng, N=20):
     return x, u, p
 
 
-CASES = [("srbd13", 0, 1.0), ("srbd13", 0, -1.0), ("srbd37", 0, 1.0), ("lip30", 0, 1.0)]
+CASES = [("srbd13", 0, 1.0), ("srbd13", 0, -1.0), ("srbd37", 0, 1.0), ("lip30", 0, 1.0), ("srbd61", 0, 1.0)]
 
 
 @pytest.mark.parametrize("name,imode,lever", CASES)
@@ -47,7 +47,7 @@ def test_dynamics_and_costs_match_sympy(name, imode, lever):
 
 
 @pytest.mark.parametrize("name,imode,lever", [("srbd13", 0, 1.0), ("srbd13", 1, -1.0), ("srbd37", 0, 1.0),
-                                              ("srbd37", 1, 1.0), ("lip30", 0, 1.0)])
+                                              ("srbd37", 1, 1.0), ("lip30", 0, 1.0), ("srbd61", 0, 1.0), ("srbd61", 1, -1.0)])
 def test_jacobians_match_finite_differences(name, imode, lever):
     m = models.make_model(name, models.RobotConsts(inertia_mode=imode, lever_sign=lever))
     rng = np.random.default_rng(3)
@@ -75,7 +75,7 @@ def test_jacobians_match_finite_differences(name, imode, lever):
 
 def test_static_input_is_an_equilibrium():
     """prb.py:243: f_z = m*9.81/force_scaling/nc on every contact gives rddot = 0 (pins gravity sign / scaling)."""
-    for name in ("srbd13", "srbd37"):
+    for name in ("srbd13", "srbd37", "srbd61"):
         m = models.make_model(name)
         x0, us = m.initial_state(), m.static_input()
         p = m.default_params(5)[0]
@@ -100,6 +100,13 @@ def test_layouts_follow_reference_literals():
     P = m.default_params(20)
     assert P.shape == (21, 19)
     np.testing.assert_allclose(P[0], [0, 0, 0, 0, 0, 0, 10, 0, 1, 0, 1, 0, 1, 0, 1, 0, 0, 0, 1])
+    # the same pattern at the code-default contact_model = 4 (prb.py:39-41): nc = 8
+    m8 = models.make_model("srbd61")
+    x0 = m8.initial_state()
+    assert x0.shape == (61,) and tuple(x0[3:7]) == (0, 0, 0, 1) and np.all(x0[31:] == 0)
+    np.testing.assert_allclose(x0[7:31], np.asarray(m8.cst.feet8).reshape(-1))
+    assert m8.static_input().shape == (48,) and m8.default_params(20).shape == (21, 27)
+    np.testing.assert_allclose(m8.default_params(20)[0], [0, 0, 0, 0, 0, 0, 10] + [0, 1] * 8 + [0, 0, 0, 1])
     lip = models.make_model("lip30")
     assert lip.initial_state().shape == (30,) and lip.static_input().shape == (15,)
     assert lip.default_params(20).shape == (21, 11)
@@ -126,6 +133,11 @@ def test_terminal_cost_has_no_constraints_and_node0_no_state_cost():
     assert n_term == 1 + 4 + 3 + 3 + 4
     assert n0 == 18 + 4 * 6 + (2 + 2 + 4 * 3)
     assert nk == n0 + n_term
+    # contact_model = 4: 6 relative-velocity constraints of 2 rows (prb.py:166-170), 8 x (1 + 2) contact rows, 8 forces
+    m8 = models.make_model("srbd61")
+    x, u, p = _rand_point(m8, rng)
+    assert m8.residual(x, None, p, 20).shape[0] == n_term
+    assert m8.residual(x, u, p, 0).shape[0] == (6 + 3 * 8) + 8 * 6 + (12 + 8 * 3)
 
 
 @pytest.mark.parametrize("name,imode,lever", [("srbd13", 0, 1.0), ("srbd13", 1, -1.0), ("srbd37", 0, 1.0)])
