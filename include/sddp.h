@@ -176,7 +176,8 @@ int  sddp_kernel_info(sddp_handle* h, int* wavefronts_per_instance, int* last_wa
 int  sddp_fetch(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats /*[B] or NULL*/);
 /* which: 0 xs [B][N+1][nx], 1 us [B][N][nu], 2 stats [B] (sddp_stats), 3 gains [slots][N][nu*(nx+1)], 4 x0 [B][nx],
  * 5 params [B][N+1][np] (the resident tensor of sddp_set_params), 6 order [last_queued] (int: the instance indices in the
- * order the last queued launch handed them out; queue_order 1 or 2 only).  The feedback gains (3) are work buffers of the queue SLOTS:
+ * order the last queued launch handed them out; queue_order 1 or 2 only), 7 slot times [last_grid][2] (uint64: the 100 MHz
+ * constant-rate clock at which each slot of the last solve launch started and found the queue empty).  The feedback gains (3) are work buffers of the queue SLOTS:
  * row b holds instance b's gains (kff then K row-major, of its last backward sweep) only after a launch that covered the
  * instances from 0 without a queue (sddp_solve / sddp_solve_device / sddp_solve_resident with B <= slots, or a range with
  * first = 0 and count <= slots); after any other launch the call returns SDDP_ERR_ARG instead of another robot's gains. */

@@ -9,7 +9,7 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 SO = int(sys.argv[4]) if len(sys.argv) > 4 else 1            # sddp_options.second_order
 WPS = int(sys.argv[5]) if len(sys.argv) > 5 else 1           # sddp_options.waves_per_simd
 batch = workload.make_batch(MODEL, N, np.arange(B))
-eng = DdpEngine(MODEL, N, B, opts=dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3, second_order=SO, waves_per_simd=WPS))
+eng = DdpEngine(MODEL, N, B, opts=dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3, second_order=SO, waves_per_simd=WPS), consts=batch["consts"])
 eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
 eng.enable_timing(True)
 x, u = eng.solve(batch["params"])

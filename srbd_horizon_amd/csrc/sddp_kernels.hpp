@@ -71,6 +71,8 @@ struct SolveArgs {
     int* qhead;
     const int* order;   // [count] absolute instance indices, or nullptr
     int* hist;          // [B] iterations of the last solve of each instance (-1: never solved): the queue-order key
+    unsigned long long* slot_t;   // [grid][2] or nullptr: constant-rate clock (wall_clock64, 100 MHz) when a slot started its first
+                                  // instance and when it found the queue empty: how long the launch drains (bench.py drain_frac)
 };
 
 // Hand-off between phases of a ONE-WAVEFRONT workgroup.  LDS (and global) accesses of one wave are performed in issue order, so a
@@ -902,6 +904,7 @@ __device__ __forceinline__ void solve_queue(const SolveArgs& A, double* s) {
     const int slot = blockIdx.x;
     const bool queued = A.qhead != nullptr;
     int i = slot;                                      // no queue: workgroup w solves instance first + w
+    if (A.slot_t && threadIdx.x == 0) A.slot_t[2 * slot] = wall_clock64();
     if (queued) {
         if (threadIdx.x == 0) i = atomicAdd(A.qhead, 1);
         i = __builtin_amdgcn_readfirstlane(i);
@@ -913,6 +916,7 @@ __device__ __forceinline__ void solve_queue(const SolveArgs& A, double* s) {
         if (threadIdx.x == 0) i = atomicAdd(A.qhead, 1);
         i = __builtin_amdgcn_readfirstlane(i);
     }
+    if (A.slot_t && threadIdx.x == 0) A.slot_t[2 * slot + 1] = wall_clock64();
 }
 
 // two builds of the same body: the register allocation is the only difference (sddp_options.waves_per_simd)

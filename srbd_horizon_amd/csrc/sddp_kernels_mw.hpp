@@ -31,16 +31,24 @@ __host__ __device__ constexpr int pad2mod4(int n) { return ((n + 1) & ~3) + 2; }
 __host__ __device__ constexpr int round_up(int n, int m) { return (n + m - 1) / m * m; }
 __host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 
-// Whether the sweep of model M runs WITHOUT the dense (Vxx F)^T tile ("W-free"): models whose tiles would
-// not fit a CU's 160 KB with it (srbd61), or every model in a -DSDDP_WFREE_ALL diagnostic build.
+// Whether the sweep of model M runs WITHOUT the dense (Vxx F)^T tile ("W-free"): the SRBD models, whose
+// [fx fu] has dense rows (ND > 0).  srbd61's tiles would not fit a CU's 160 KB with the tile; srbd37 drops from 63.8 to 50.9 KB and
+// gains 14 % at two workgroups per CU (the W phase becomes a compact 111 x 7 product).  lip30 (no dense rows: the tile IS the
+// product) keeps it: measured neutral to - 1 % without.  -DSDDP_WFREE_ALL / -DSDDP_WFREE_NONE: diagnostic builds.
 template <class M>
 constexpr bool mw_wfree() {
-#ifdef SDDP_WFREE_ALL
+#if defined(SDDP_WFREE_ALL)
     return true;
-#else
+#elif defined(SDDP_WFREE_NONE)
     return M::NX > 40;
+#else
+    return M::ND > 0;
 #endif
 }
+
+#ifndef SDDP_MW_W2_WAVES
+#define SDDP_MW_W2_WAVES 2      // diagnostic: 3 = the half-register-file build capped at a third of the register file instead
+#endif
 
 template <class M>
 struct LdsMW {
@@ -837,7 +845,7 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
         SDDP_TICK(11)
         // ---- B: every wave computes UPW rows of u = u_k + alpha kff + K (x - x_k)
         if (wave == kWavesMW - 1 && lane < NX) xn[k * NX + lane] = s[L::RO_X + lane * kWave + store_lane];
-        {
+        if constexpr (NX <= 40) {
             double dx[NX];
             if (!OPEN_LOOP) {
                 // x - x_k in chunks of CH entries, the next chunk's reads in flight behind the subtractions of this one
@@ -903,6 +911,51 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
                         if (u * HU + j < NX) acc = fma(gb[t & 1][j], dx[u * HU + j], acc);
                     if (u == NUNIT - 1 && wave * UPW + r < NU) U[wave * UPW + r] = acc;
                 }
+            }
+        }
+        else {
+            // Wide models (nx = 61): x - x_k does not fit the registers beside the gain units (all of it live: 61 doubles spill, and
+            // the spills of a whole workgroup fall out of the L2).  Chunks of CH columns in a RUNTIME loop, the wave's UPW rows
+            // inside: x - x_k of one chunk lives in CH registers, every row keeps one accumulator, the gain rows are read CH entries at
+            // a time one row ahead.  Per row the sum still runs over the columns in ascending order, starting from u_k + alpha kff.
+            constexpr int CH = 10, NCH = (NX + CH - 1) / CH;
+            static_assert(NCH * CH <= SG + CH, "the last chunk reads at most one unit past a gain row (finite staged data)");
+            double acc[UPW];
+#pragma unroll
+            for (int r = 0; r < UPW; ++r) {
+                const int i = wave * UPW + r < NU ? wave * UPW + r : NU - 1;
+                const double ub = sb[L::SB_U + i];
+                if (OPEN_LOOP) { if (wave * UPW + r < NU) U[wave * UPW + r] = ub; }
+                else acc[r] = fma(alpha, kf[i], ub);
+            }
+            if (!OPEN_LOOP) {
+#pragma unroll 1
+                for (int cI = 0; cI < NCH; ++cI) {
+                    const int c0 = cI * CH;
+                    double dx[CH], xv[CH], xkv[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) { xv[j] = X[min(c0 + j, NX - 1)]; xkv[j] = sb[L::SB_X + min(c0 + j, NX - 1)]; }
+                    pin_regs(xv);
+                    pin_regs(xkv);
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) dx[j] = c0 + j < NX ? xv[j] - xkv[j] : 0.0;     // columns past nx: multiplied by 0
+                    double gb[2][CH];
+                    auto load_unit = [&](int r, double (&dst)[CH]) {
+                        const int i = wave * UPW + r < NU ? wave * UPW + r : NU - 1;
+                        load_run<CH>(kb + i * SG + c0, dst);                                      // c0, SG even: ds_read_b128
+                    };
+                    load_unit(0, gb[0]);
+#pragma unroll
+                    for (int r = 0; r < UPW; ++r) {
+                        if (r + 1 < UPW) load_unit(r + 1, gb[(r + 1) & 1]);
+                        pin_regs(gb[r & 1]);
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) acc[r] = fma(gb[r & 1][j], dx[j], acc[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < UPW; ++r)
+                    if (wave * UPW + r < NU) U[wave * UPW + r] = acc[r];
             }
         }
         __syncthreads();
@@ -1094,13 +1147,13 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
 
 // work queue over the resident workgroups (see solve_queue in sddp_kernels.hpp); the queue position travels through LDS
 template <class M>
-__global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
-    extern __shared__ __attribute__((aligned(16))) double s[];
+__device__ __forceinline__ void solve_queue_mw(const SolveArgs& A, double* s) {
     // the queue position lives in a control word of the dynamic LDS block (CTL + 15), so that the occupancy query and the
     // dynamic-LDS attribute cover every byte of LDS the kernel uses
     int* q_pos = reinterpret_cast<int*>(s + LdsMW<M>::CTL + 15);
     const int slot = blockIdx.x;
     const bool queued = A.qhead != nullptr;
+    if (A.slot_t && threadIdx.x == 0) A.slot_t[2 * slot] = wall_clock64();
     if (queued && threadIdx.x == 0) *q_pos = atomicAdd(A.qhead, 1);
     __syncthreads();
     int i = queued ? *q_pos : slot;
@@ -1114,29 +1167,20 @@ __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
         i = *q_pos;
         __syncthreads();
     }
+    if (A.slot_t && threadIdx.x == 0) A.slot_t[2 * slot + 1] = wall_clock64();
+}
+template <class M>
+__global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double s[];
+    solve_queue_mw<M>(A, s);
 }
 
-// the same body capped at half the register file: two workgroups per CU where the tiles of two instances fit its LDS (lip30:
-// 2 x 77 KB); sddp_options.waves_per_simd = 2 picks it, results are identical
+// the same body capped at half the register file: two workgroups per CU where the tiles of two instances fit its LDS;
+// sddp_options.waves_per_simd = 2 picks it, results are identical
 template <class M>
-__global__ __launch_bounds__(kThreadsMW) __attribute__((amdgpu_waves_per_eu(2))) void solve_kernel_mw_w2(SolveArgs A) {
+__global__ __launch_bounds__(kThreadsMW) __attribute__((amdgpu_waves_per_eu(SDDP_MW_W2_WAVES))) void solve_kernel_mw_w2(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double s[];
-    int* q_pos = reinterpret_cast<int*>(s + LdsMW<M>::CTL + 15);
-    const int slot = blockIdx.x;
-    const bool queued = A.qhead != nullptr;
-    if (queued && threadIdx.x == 0) *q_pos = atomicAdd(A.qhead, 1);
-    __syncthreads();
-    int i = queued ? *q_pos : slot;
-    __syncthreads();
-    while (i < A.count) {
-        const int b = (queued && A.order) ? A.order[i] : A.first + i;
-        solve_instance_mw<M>(A, s, b, slot);
-        if (!queued) break;
-        if (threadIdx.x == 0) *q_pos = atomicAdd(A.qhead, 1);
-        __syncthreads();
-        i = *q_pos;
-        __syncthreads();
-    }
+    solve_queue_mw<M>(A, s);
 }
 
 template <class M>

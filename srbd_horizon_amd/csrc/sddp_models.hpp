@@ -864,7 +864,9 @@ struct SrbdModel {
                 case V_RD: if (state) v = 2 * c.w_rd; break;
                 case V_W: if (state) v = 2 * c.w_w; break;
                 case V_C:
-                    if (state && ai < 2) { if (ci == cj) v += 2 * c.w_rel; else if (ci + 2 == cj || cj + 2 == ci) v -= 2 * c.w_rel; }
+                    if (state && ai < 2 && ci < 4 && cj < 4) {   // rel_pos names contact points 0, 2 and 1, 3 (prb.py:192-199), whatever nc is
+                        if (ci == cj) v += 2 * c.w_rel; else if (ci + 2 == cj || cj + 2 == ci) v -= 2 * c.w_rel;
+                    }
                     if (stage && ci == cj && ai == 2) v += 2 * c.w_pen;
                     break;
                 case V_CD:

@@ -242,6 +242,19 @@ class DdpEngine:
 
         return torch.as_tensor(_Dev(), device=torch.device("cuda", torch.cuda.current_device())).cpu().numpy().copy()
 
+    def slot_times(self):
+        """[grid, 2] uint64: when each slot of the last solve launch started its first instance and when it found the queue empty
+        (100 MHz constant-rate clock); waits for the stream."""
+        import torch
+        self.synchronize()
+        ptr, nbytes = self.device_buffer(7)
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+        t = torch.as_tensor(_Dev(), device=torch.device("cuda", torch.cuda.current_device())).cpu().numpy().copy()
+        return t.view(np.uint64).reshape(-1, 2)
+
     def queue_info(self):
         """(slots the work buffers exist for, grid of the last launch, queue length of the last launch or 0)."""
         a, b, c = C.c_int(), C.c_int(), C.c_int()

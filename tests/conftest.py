@@ -27,3 +27,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def report_parity(record_property, key: str, **counts):
+    """Parity bookkeeping that survives `pytest -q`: the counts go into the junit properties of the test AND into a warning, which
+    pytest lists in its warnings summary (so the driver's record of the GPU run shows how far from its allowance a test ran)."""
+    import json
+    import warnings
+    for k, v in counts.items():
+        record_property(f"{key}.{k}", v)
+    warnings.warn(UserWarning(f"PARITY-COUNT {key} " + json.dumps(counts, sort_keys=True, default=str)))

@@ -39,14 +39,27 @@ def test_no_timed_instance_is_solved_before_the_timed_region():
     """every step solves instances of its own; the warm-up blocks are disjoint from every rank's timed blocks,
     ranks do not share blocks, and the shipped default is the history-free queue order."""
     for world, steps, warmup in ((1, 20, 5), (8, 20, 5), (2, 96, 16), (1, 1, 0), (4, 3, 7)):
-        timed = [bench.seed_block(r, world, steps, warmup, "timed", i) for r in range(world) for i in range(steps)]
+        timed = [bench.seed_block(r, world, steps, warmup, "timed", i, run=k) for k in range(bench.RUNS) for r in range(world) for i in range(steps)]
         warm = [bench.seed_block(r, world, steps, warmup, "warmup", i) for r in range(world) for i in range(warmup)]
-        assert len(set(timed)) == world * steps and len(set(warm)) == world * warmup
+        assert len(set(timed)) == bench.RUNS * world * steps and len(set(warm)) == world * warmup     # the timed regions share nothing either
         assert not set(timed) & set(warm)
-        assert sorted(timed) == list(range(world * steps))            # rank r owns the contiguous blocks r*steps .. r*steps+steps-1
+        assert sorted(timed) == list(range(bench.RUNS * world * steps))   # region k, rank r owns the contiguous blocks (k*world + r)*steps ..
+        assert sorted(timed[:world * steps]) == list(range(world * steps))
     src = open(bench.__file__).read()
     assert '"--queue-order", type=int, default=2' in src              # `value` = largest initial cost first: no history
     assert "replay_history_order_solves_per_s" in src                 # the foreknowledge figure is an extra, named as a replay
+
+
+def test_drain_profile_from_slot_clocks():
+    """drain_frac = share of a launch during which fewer than half of its slots still hold an instance (100 MHz slot clocks)"""
+    t = np.zeros((4, 2), dtype=np.uint64)
+    t[:, 0] = 1000
+    t[:, 1] = [1000 + 100, 1000 + 200, 1000 + 300, 1000 + 1000]       # one straggler: the median slot is dry at 200 of 1000
+    d = bench.drain_profile(t)
+    assert abs(d["drain_frac"] - 0.8) < 1e-12 and abs(d["idle_slot_time_frac"] - (1 - 400 / 1000)) < 1e-12 and d["slots"] == 4
+    t[:, 1] = 1000 + 500                                               # perfectly balanced launch
+    d = bench.drain_profile(t)
+    assert d["drain_frac"] == 0.0 and d["idle_slot_time_frac"] == 0.0
 
 
 def test_queue_model_reproduces_the_design_table():

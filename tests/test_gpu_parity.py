@@ -17,6 +17,7 @@ from srbd_horizon_amd.engine import DdpEngine, eval_knots
 pytestmark = pytest.mark.gpu
 
 MODELS = ["srbd13", "srbd37", "lip30"]
+BENCH_BATCH_ALLOWED = 3       # instances of the 1024 of the bench batch that may take another iteration count than the C oracle
 
 
 def _oracle_model(name, consts=None):
@@ -366,7 +367,7 @@ def test_closed_loop_tracking_holds_under_a_per_tick_iteration_budget():
         assert dev < 0.02, (model, dev)
 
 
-def test_whole_bench_batch_matches_the_c_oracle():
+def test_whole_bench_batch_matches_the_c_oracle(record_property):
     """All 1024 instances of the bench batch (BASELINE configs[2]) against the plain-C restatement of the oracle
     (oracle/c, pinned to the numpy oracle by tests/test_oracle_c.py): same iteration count and, at the north_star tolerance
     (1e-4 l-inf), the same trajectory -- stragglers included (up to 93 iterations, step lengths down to 2^-9, i.e. the
@@ -384,8 +385,12 @@ def test_whole_bench_batch_matches_the_c_oracle():
     same = st["iters"] == it_o
     print(f"bench batch: {int((~same).sum())} of {B} instances with a different iteration count than the C oracle "
           f"(GPU {st['iters'][~same].tolist()} oracle {it_o[~same].tolist()}); max l-inf x {np.max(np.abs(x[same] - xo[same])):.2e}")
-    # chaotic early iterations of a few hard instances may pick another step length on a last-bit difference: allow 1 %
-    assert same.mean() >= 0.99, f"{(~same).sum()} instances with a different iteration count"
+    from tests.conftest import report_parity
+    report_parity(record_property, "bench_batch_1024", differ=int((~same).sum()), allowed=BENCH_BATCH_ALLOWED, gpu_iters=st["iters"][~same].tolist(),
+                  oracle_iters=it_o[~same].tolist())
+    # chaotic early iterations of a few hard instances may pick another step length on a last-bit difference.  The allowance is
+    # what the shipped build shows (PARITY-COUNT in the warnings summary of the GPU run) + 50 %, not a round percentage
+    assert int((~same).sum()) <= BENCH_BATCH_ALLOWED, f"{(~same).sum()} instances with a different iteration count"
     assert st["iters"].max() >= 60 and st["rollouts"].max() > st["iters"].max()       # the fallback path did run
     ex = np.max(np.abs(x[same] - xo[same]), axis=(1, 2))
     eu = np.max(np.abs(u[same] - uo[same]), axis=(1, 2))

@@ -18,6 +18,7 @@ from srbd_horizon_amd.fleet import FleetQueue
 pytestmark = pytest.mark.gpu
 
 OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsrbd_example.py:55-58
+SHARD_ALLOWED, TOTAL_ALLOWED = 6, 24    # configs[3]: instances per rank shard / of all 8192 that may take another iteration count
 
 
 def _engine(model, N, B, max_slots=None, **over):
@@ -97,7 +98,7 @@ def test_non_finite_options_are_rejected():
             DdpEngine("srbd13", 30, 1, opts=dict(OPTS, **{k: v}))
 
 
-def test_configs3_all_eight_rank_shards_match_the_c_oracle():
+def test_configs3_all_eight_rank_shards_match_the_c_oracle(record_property):
     """BASELINE configs[3]: 8192 instances = the shards rank r = 0..7 of bench.py solve (seeds r * 1024 + arange(1024)), here
     through ONE handle on one GPU: a queue of 8192 instances on the device's resident slots, against the plain-C oracle."""
     N, B, R = 30, 1024, 8
@@ -114,8 +115,12 @@ def test_configs3_all_eight_rank_shards_match_the_c_oracle():
     per_shard = [int((~same[r * B:(r + 1) * B]).sum()) for r in range(R)]
     print(f"configs[3]: {int((~same).sum())} of {R * B} instances with a different iteration count, per rank shard {per_shard}; "
           f"slots {slots}; iterations mean {st['iters'].mean():.2f} max {st['iters'].max()}")
-    # chaotic early iterations of a few hard instances may pick another step length on a last-bit difference: allow 1 % per shard
-    assert max(per_shard) <= B // 100, per_shard
+    from tests.conftest import report_parity
+    report_parity(record_property, "configs3_8192", differ=int((~same).sum()), per_shard=per_shard, allowed_per_shard=SHARD_ALLOWED,
+                  allowed_total=TOTAL_ALLOWED, gpu_iters=st["iters"][~same].tolist(), oracle_iters=it_o[~same].tolist())
+    # chaotic early iterations of a few hard instances may pick another step length on a last-bit difference.  The allowances are
+    # what the shipped build shows (PARITY-COUNT in the warnings summary of the GPU run) + 50 %, not a round percentage
+    assert max(per_shard) <= SHARD_ALLOWED and int((~same).sum()) <= TOTAL_ALLOWED, per_shard
     conv_o = so[:, 2].astype(int) == 1
     n_unconv = int((~conv_o).sum())
     print(f"configs[3]: {n_unconv} instances end at max_iters in the oracle (status {np.unique(so[~conv_o, 6]).tolist()}), "
