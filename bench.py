@@ -342,6 +342,8 @@ def main():
         "value_note": f"median of {RUNS} timed regions of exactly {steps} steps each, every region on seed blocks of its own "
                       "(value_runs: all of them, in execution order; ms_per_step, mean_iters, roofline and last_launch are the median region's)",
         "drain": med["drain"], "drain_runs": [r["drain"] for r in regions],
+        "mean_iters_runs": [r["iters"] / n_solves for r in regions],
+        "kernel_ms_runs": [r["ksum"] / max(r["kcnt"], 1) for r in regions],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"SRBD N={N} nx=13 nu=6, batch={B} independent MPC instances per GPU and step "
                                "(BASELINE configs[2]; x8 GPUs = configs[3]), cold start, whole line-search ladder "
@@ -699,10 +701,10 @@ def single_instance_extras(N, opts, workload, DdpEngine):
     # the reference's own example loops (its real problem sizes, ns = 20, T = 1 s): dsrbd_example.py (srbd37) and
     # dlip_example.py (lip30, configs[0]); 10 warm-up + 100 timed ticks each
     out["ms_per_mpc_tick_reference_models"] = {}
-    for mname, ns in (("srbd37", 20), ("lip30", 20), ("srbd37", 60)):
+    for mname, ns in (("srbd37", 20), ("lip30", 20), ("srbd37", 60), ("srbd61", 20)):
         lp = MpcLoop(mname, ns, warm_start="device")
         tms, its = [], []
-        nt = 110 if ns == 20 else 60
+        nt = 50 if mname == "srbd61" else (110 if ns == 20 else 60)
         for i in range(nt):
             t1 = time.perf_counter()
             lp.tick("walking", (1.0, 0.0))
@@ -721,6 +723,10 @@ def single_instance_extras(N, opts, workload, DdpEngine):
     out["srbd37_n20_batch_one_workgroup_per_cu"] = mw_batch("srbd37", 20, 1024, opts, workload, DdpEngine)
     # BASELINE configs[0]'s model as a batch
     out["lip30_n20_batch"] = mw_batch("lip30", 20, 4096, w2, workload, DdpEngine)
+    # the reference problem at the contact configuration its code defaults to (contact_model = 4: nx 61, nu 48; prb.py:39-41):
+    # one workgroup per CU (its tiles take 145 KB of the CU's 160)
+    out["srbd61_n20_batch"] = mw_batch("srbd61", 20, 1024, opts, workload, DdpEngine)
+    out["srbd61_n60_batch"] = mw_batch("srbd61", 60, 512, opts, workload, DdpEngine, reps=2)
     return out
 
 

@@ -4,7 +4,7 @@
 # Headline kernel (solve_kernel_w2<srbd13>): 1 kernel trace + stats, 3 separate PMC passes (never combined with trace domains)
 # of the command the driver runs (--steps 20 --warmup 5), then its full bench line.  4-wavefront kernel (solve_kernel_mw<srbd37>):
 # the same four passes over one cold batch at the reference's own size (ns = 20) and at BASELINE configs[4] (N = 60), two
-# workgroups per CU (waves_per_simd = 2).
+# workgroups per CU (waves_per_simd = 2); and over the same problem at its code-default contact_model = 4 (srbd61, one per CU).
 set -e
 R=${1:-r03}
 export TMPDIR=/tmp
@@ -24,6 +24,7 @@ passes() {   # passes <tag> <command...>: trace + FETCH + WRITE + SQ, each its o
 passes "" python3 bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-extras
 passes mw_srbd37_n20_ python3 profiles/run_mw_batch.py srbd37 20 2048 2
 passes mw_srbd37_n60_ python3 profiles/run_mw_batch.py srbd37 60 1024 2
+passes mw_srbd61_n20_ python3 profiles/run_mw_batch.py srbd61 20 1024 1
 python3 bench.py --steps $STEPS --warmup 5 > $O/bench.log 2> $O/bench.err
 echo "bench done"
 python3 profiles/make_summary.py $R $O $STEPS | tee $O/summary.txt

@@ -41,21 +41,25 @@ def kernel_set(tag, kname, suffix):
 h = kernel_set("", "solve_kernel", "bench")
 tj = last_json(f"{O}/trace.log")
 nt = tj["config"]["launches_timed"]
-f, w = h["FETCH_SIZE"]["per_dispatch"][-nt:], h["WRITE_SIZE"]["per_dispatch"][-nt:]      # the timed launches come last
+runs = len(tj.get("value_runs", [1]))                      # timed regions of the command (bench.py RUNS), nt launches each
+f, w = h["FETCH_SIZE"]["per_dispatch"][-runs * nt:], h["WRITE_SIZE"]["per_dispatch"][-runs * nt:]      # the timed launches come last
 fm, wm = sum(f) / len(f), sum(w) / len(w)
 summary = dict(h)
 summary["traffic_bytes_per_launch"] = (2 * fm + wm) * 1024
 summary["traffic_bytes_per_launch_uncorrected"] = (fm + wm) * 1024
 summary["batches_per_launch"] = steps / nt
 dur = h["rocprof_dispatch_ms"]
-summary["traced_run"] = {"launches": len(dur), "warmup_launches": len(dur) - nt, "rocprof_ms_timed": dur[-nt:],
-                         "rocprof_mean_ms_timed": sum(dur[-nt:]) / nt, "hip_event_mean_ms_timed": tj["roofline"]["kernel_ms"]}
+summary["traced_run"] = {"launches": len(dur), "warmup_launches": len(dur) - runs * nt, "rocprof_ms_timed": dur[-runs * nt:],
+                         "rocprof_mean_ms_timed": sum(dur[-runs * nt:]) / (runs * nt), "hip_event_ms_by_region": tj.get("kernel_ms_runs"),
+                         "hip_event_mean_ms_median_region": tj["roofline"]["kernel_ms"],
+                         "note": "the HIP-event interval of a launch brackets its queue-ordering pre-pass (cost-key kernel + device sort, "
+                                 "~0.1 ms) as well as the solve kernel; rocprof_ms_timed is the solve kernel alone"}
 n_inst = steps * 1024 / nt
-it = tj["mean_iters"]
+it = (tj.get("mean_iters_runs") or [tj["mean_iters"]])[-1]                      # the last dispatch belongs to the last timed region
 sq = h["SQ_last_dispatch"]
 summary["per_instance_iteration"] = {k: v / (n_inst * it) for k, v in sq.items() if k.startswith("SQ_INSTS")}
 summary["note"] = (f"rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_* each in its own run) of `python3 bench.py --steps {steps} --warmup 5 "
-                   "--no-cpu-baseline --no-extras` (one warm-up launch of 5 batches, then the timed launch(es) of distinct instances, each a "
+                   "--no-cpu-baseline --no-extras` (one warm-up launch of 5 batches, then the timed launches -- one per timed region -- of distinct instances, each a "
                    "work queue on the resident wavefronts); traffic = the timed launches; FETCH/WRITE_SIZE in KiB; gfx950 correction per "
                    "MI355X_MICROARCH.md (HBM): FETCH_SIZE doubled (calibrated for 16 B/lane streams; this kernel reads 8 B/lane, so the "
                    "uncorrected figure is also given).  Kernel = solve_kernel_w2<SrbdModel<2,false>>, N=30.")
@@ -68,7 +72,7 @@ open(os.path.join(out_dir, "bench_line_traced_run.json"), "w").write(json.dumps(
 
 # ---- 4-wavefront kernel: one cold batch per configuration --------------------------------------------------------------------
 mw = {}
-for tag in ("mw_srbd37_n20_", "mw_srbd37_n60_"):
+for tag in ("mw_srbd37_n20_", "mw_srbd37_n60_", "mw_srbd61_n20_"):
     if not os.path.isdir(f"{O}/{tag}trace"):
         continue
     k = kernel_set(tag, "solve_kernel_mw", tag.rstrip("_"))

@@ -94,7 +94,7 @@ SolveArgs make_args(sddp_handle* h, const double* d_params) {
     a.c = h->dc; a.o = h->opts; a.N = h->N; a.B = h->B;
     a.x0 = h->x0; a.P = d_params; a.xs = h->xs; a.us = h->us; a.xn = h->xn; a.un = h->un; a.xc = h->xc; a.uc = h->uc; a.dft = h->dft;
     a.gains = h->gains; a.rec = h->rec; a.stats = h->stats; a.scal = h->scal; a.alpha = 0.0; a.mu = 0.0;
-    a.first = 0; a.count = h->B; a.qhead = nullptr; a.order = nullptr; a.hist = h->hist; a.slot_t = h->slot_t;
+    a.first = 0; a.count = h->B; a.qhead = nullptr; a.order = nullptr; a.hist = h->hist;
     return a;
 }
 
@@ -270,9 +270,9 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (e == hipSuccess) e = alloc((void**)&h->rec, W * (N + 1) * d.nrec * D);
     if (e == hipSuccess) e = alloc((void**)&h->scal, size_t(batch) * kScal * D);
     if (e == hipSuccess) e = alloc((void**)&h->qhead, sizeof(int));
-    if (e == hipSuccess) e = alloc((void**)&h->slot_t, std::max<size_t>(W, 1) * 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = alloc((void**)&h->order, size_t(batch) * sizeof(int));
-    if (e == hipSuccess) e = alloc((void**)&h->hist, size_t(batch) * sizeof(int));
+    // hist [B] (padded to a multiple of two ints), then the slot clocks [W][2] uint64 (SolveArgs::slot_clock)
+    if (e == hipSuccess) e = alloc((void**)&h->hist, size_t((batch + 1) & ~1) * sizeof(int) + std::max<size_t>(W, 1) * 2 * sizeof(unsigned long long));
     // on the handle's own stream, and complete before sddp_create returns: a null-stream hipMemset is asynchronous to the host
     // and is NOT ordered with a non-blocking stream, so it could land in the middle of the first solve (seen once as a
     // different iteration count on a 1-knot problem)
@@ -299,7 +299,7 @@ void sddp_destroy(sddp_handle* h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->x0, h->P, h->xs /* | us | stats */, h->xn, h->un, h->xc, h->uc, h->tick_in, h->step_buf, h->dft, h->gains, h->rec, h->scal,
-                    h->qhead, h->slot_t, h->order, h->hist, h->qkey, h->qkey2, h->order_in, h->sort_tmp};
+                    h->qhead, h->order, h->hist, h->qkey, h->qkey2, h->order_in, h->sort_tmp};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->pinned) (void)hipHostFree(h->pinned);
@@ -656,7 +656,7 @@ int sddp_device_ptr(sddp_handle* h, int which, void** ptr, long long* bytes) {
             *ptr = h->order; n = (long long)(size_t(h->last_queued) * sizeof(int)); break;
         case 7:   // per slot of the last solve launch: (start, queue found empty) on the 100 MHz constant-rate clock
             if (h->last_grid < 1) return fail(h, SDDP_ERR_ARG, "no solve launch yet");
-            *ptr = h->slot_t; n = (long long)(size_t(h->last_grid) * 2 * sizeof(unsigned long long)); break;
+            *ptr = h->hist + ((h->B + 1) & ~1); n = (long long)(size_t(h->last_grid) * 2 * sizeof(unsigned long long)); break;
         default: return fail(h, SDDP_ERR_ARG, "unknown buffer id");
     }
     if (bytes) *bytes = n;

@@ -72,9 +72,9 @@ struct sddp_handle {
     int wslots = 0;                 // slots the work buffers (xn un xc uc dft gains rec) are allocated for = min(B, resident capacity)
     int cus = 0;
     int* qhead = nullptr;           // device queue head
-    unsigned long long* slot_t = nullptr;   // [wslots][2] start / queue-empty clock of every slot of the last launch (SolveArgs::slot_t)
     int* order = nullptr;           // [B] queue order of the next launch
-    int* hist = nullptr;            // [B] iterations of each instance's previous solve (-1: none)
+    int* hist = nullptr;            // [B] iterations of each instance's previous solve (-1: none), then the slot clocks [wslots][2]
+                                    // (uint64, SolveArgs::slot_clock)
     // cold-queue order (queue_order = 2): initial-cost keys of the launch, their sorted copy, the unsorted index list, sort scratch;
     // allocated together at sddp_create when the option asks for it, or on the first launch that needs them (all or nothing)
     double *qkey = nullptr, *qkey2 = nullptr;

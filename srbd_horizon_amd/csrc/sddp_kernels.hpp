@@ -70,9 +70,13 @@ struct SolveArgs {
     int first, count;
     int* qhead;
     const int* order;   // [count] absolute instance indices, or nullptr
-    int* hist;          // [B] iterations of the last solve of each instance (-1: never solved): the queue-order key
-    unsigned long long* slot_t;   // [grid][2] or nullptr: constant-rate clock (wall_clock64, 100 MHz) when a slot started its first
-                                  // instance and when it found the queue empty: how long the launch drains (bench.py drain_frac)
+    int* hist;          // [B] iterations of the last solve of each instance (-1: never solved): the queue-order key; behind it (no
+                        // kernel argument of its own: the solve kernels live on their scalar registers) the slot clocks [slots][2]:
+                        // constant-rate clock (wall_clock64, 100 MHz) when a slot started its first instance and when it found the
+                        // queue empty -- how long a launch drains (bench.py drain_frac)
+    __device__ __forceinline__ unsigned long long* slot_clock(int slot) const {
+        return reinterpret_cast<unsigned long long*>(hist + ((B + 1) & ~1)) + 2 * slot;
+    }
 };
 
 // Hand-off between phases of a ONE-WAVEFRONT workgroup.  LDS (and global) accesses of one wave are performed in issue order, so a
@@ -904,7 +908,9 @@ __device__ __forceinline__ void solve_queue(const SolveArgs& A, double* s) {
     const int slot = blockIdx.x;
     const bool queued = A.qhead != nullptr;
     int i = slot;                                      // no queue: workgroup w solves instance first + w
-    if (A.slot_t && threadIdx.x == 0) A.slot_t[2 * slot] = wall_clock64();
+#ifndef SDDP_NO_SLOT_CLOCK
+    if (threadIdx.x == 0) A.slot_clock(slot)[0] = wall_clock64();
+#endif
     if (queued) {
         if (threadIdx.x == 0) i = atomicAdd(A.qhead, 1);
         i = __builtin_amdgcn_readfirstlane(i);
@@ -916,7 +922,9 @@ __device__ __forceinline__ void solve_queue(const SolveArgs& A, double* s) {
         if (threadIdx.x == 0) i = atomicAdd(A.qhead, 1);
         i = __builtin_amdgcn_readfirstlane(i);
     }
-    if (A.slot_t && threadIdx.x == 0) A.slot_t[2 * slot + 1] = wall_clock64();
+#ifndef SDDP_NO_SLOT_CLOCK
+    if (threadIdx.x == 0) A.slot_clock(slot)[1] = wall_clock64();
+#endif
 }
 
 // two builds of the same body: the register allocation is the only difference (sddp_options.waves_per_simd)

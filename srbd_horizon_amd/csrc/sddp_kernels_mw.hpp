@@ -1153,7 +1153,7 @@ __device__ __forceinline__ void solve_queue_mw(const SolveArgs& A, double* s) {
     int* q_pos = reinterpret_cast<int*>(s + LdsMW<M>::CTL + 15);
     const int slot = blockIdx.x;
     const bool queued = A.qhead != nullptr;
-    if (A.slot_t && threadIdx.x == 0) A.slot_t[2 * slot] = wall_clock64();
+    if (threadIdx.x == 0) A.slot_clock(slot)[0] = wall_clock64();
     if (queued && threadIdx.x == 0) *q_pos = atomicAdd(A.qhead, 1);
     __syncthreads();
     int i = queued ? *q_pos : slot;
@@ -1167,7 +1167,7 @@ __device__ __forceinline__ void solve_queue_mw(const SolveArgs& A, double* s) {
         i = *q_pos;
         __syncthreads();
     }
-    if (A.slot_t && threadIdx.x == 0) A.slot_t[2 * slot + 1] = wall_clock64();
+    if (threadIdx.x == 0) A.slot_clock(slot)[1] = wall_clock64();
 }
 template <class M>
 __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
