@@ -369,7 +369,7 @@ def main():
         "fp64_vector_peak_frac": tot_iters / elapsed * 0.85e6 * (N / 30.0) / 78.6e12,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": eng.kernel_info()["kernel"], "kernel_ms": kms,
+                     "kernel": eng.kernel_info()["kernel"], "resources": eng.kernel_info().get("resources"), "kernel_ms": kms,
                      "launches": int(kcnt), "algorithmic_bytes_per_launch": abytes_launch,
                      "note": "achieved = algorithmic bytes of the average timed launch (SURVEY 8(d) bytes per solve, from the iteration "
                              "and rollout counts of every instance of the timed region) / its HIP-event duration on the launch stream "
@@ -421,6 +421,13 @@ def main():
         out["one_batch_in_flight_ms_per_step"] = 1e3 * el1 / n1
         del f_lat, e_lat
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # The tick loops below report a p99 / max per tick.  CPython's generation-2 garbage collection walks every tracked object
+        # of the process (31 ms with torch imported) once per ~70 k container allocations: the "one-time 20-45 ms stall" of rounds
+        # 2-3 (profiles/r04/experiments/host_stall_hiptrace.txt: no HIP call is in flight during it).  A real-time loop freezes
+        # the set-up objects out of the collector's reach; so does this one.
+        import gc
+        gc.collect()
+        gc.freeze()
         batch = workload.make_batch("srbd13", N, np.arange(B))
         out.update(single_instance_extras(N, opts, workload, DdpEngine))
         out["ms_per_fleet_tick"] = fleet_tick(N, B, opts, workload, DdpEngine)
@@ -476,7 +483,7 @@ def mw_batch(model, N, B, opts, workload, DdpEngine, reps=3):
     slots, grid, queued = e.queue_info()
     return {"waves_per_simd": int(opts.get("waves_per_simd", 1)), "solves_per_s": B / min(wall), "kernel_solves_per_s": B / (kms * 1e-3), "batch": B, "horizon_N": N, "mean_iters": float(np.mean(iters)),
             "max_iters": int(iters.max()), "mean_rollouts": float(np.mean(roll)), "converged_frac": float(np.mean(st["converged"] == 1)),
-            "slots": slots, "grid": grid, "kernel": e.kernel_info()["kernel"], "kernel_ms": kms,
+            "slots": slots, "grid": grid, "kernel": e.kernel_info()["kernel"], "resources": e.kernel_info().get("resources"), "kernel_ms": kms,
             "algorithmic_bytes": ab, "achieved_gbs": ab / (kms * 1e-3) / 1e9, "hbm_frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "fp64_algorithmic_tflops": float(iters.sum()) * flop_it / (kms * 1e-3) / 1e12,
             "fp64_vector_peak_frac": float(iters.sum()) * flop_it / (kms * 1e-3) / 78.6e12,
@@ -613,9 +620,9 @@ def fleet_tick_reference_model(opts, workload, DdpEngine, model="srbd37", N=20, 
             "note": f"{model} N={N}: {B} robots of the reference's own problem, warm-started ticks, sddp_advance + sddp_solve_resident_first "
                     "(first input, next state, cost, iterations, status of every robot over PCIe), two workgroups per CU; CPU = the C port, "
                     "OpenMP over robots, the same ticks (the first of its ticks warms the threads' work arrays up and is left out of the median).  "
-                    "gpu_kernel_ms_*: the solve kernel alone by HIP events -- one tick per process shows a host-side stall of 20-45 ms inside the "
-                    "launch / wait (the HIP runtime growing a submission pool at a fixed launch count) while its kernel takes as long as every other: "
-                    "that is the p99 / max of this short run"}
+                    "gpu_kernel_ms_*: the solve kernel alone by HIP events.  (Rounds 2-3 saw one tick per process with a host-side stall of "
+                    "20-45 ms: CPython's generation-2 garbage collection, not the HIP runtime -- bench.py now freezes the set-up objects, "
+                    "profiles/r04/experiments/host_stall_hiptrace.txt)"}
 
 
 def tick_curve(N, opts, workload, DdpEngine, batches=(1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024), ticks=24, cpu_ticks=3):

@@ -172,6 +172,10 @@ int  sddp_queue_info(sddp_handle* h, int* slots, int* last_grid, int* last_queue
  * (1: full register file, 2: the `_w2` half-register-file build -- a handle asked for 2 falls back to 1 where that gains no
  * resident workgroup) and the model name the kernels are instantiated for.  Any pointer may be NULL. */
 int  sddp_kernel_info(sddp_handle* h, int* wavefronts_per_instance, int* last_waves_per_simd, const char** model_name);
+/* what that kernel build takes from a CU, read from its code object (hipFuncGetAttributes): architected vector registers per
+ * lane, scratch (spill) bytes per lane, LDS bytes per workgroup (static + dynamic), and how many of its workgroups the device keeps
+ * resident per CU (the occupancy query the queue's slot count comes from).  Any pointer may be NULL. */
+int  sddp_kernel_resources(sddp_handle* h, int* vgprs, int* scratch_bytes_per_lane, int* lds_bytes, int* workgroups_per_cu);
 /* results of the last device solve (x, u, stats of the whole batch) to host pointers; waits for the stream */
 int  sddp_fetch(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats /*[B] or NULL*/);
 /* which: 0 xs [B][N+1][nx], 1 us [B][N][nu], 2 stats [B] (sddp_stats), 3 gains [slots][N][nu*(nx+1)], 4 x0 [B][nx],

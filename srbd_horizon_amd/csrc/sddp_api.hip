@@ -443,6 +443,18 @@ int sddp_kernel_info(sddp_handle* h, int* wavefronts_per_instance, int* last_wav
     return SDDP_OK;
 }
 
+int sddp_kernel_resources(sddp_handle* h, int* vgprs, int* scratch_bytes_per_lane, int* lds_bytes, int* workgroups_per_cu) {
+    if (!h) return SDDP_ERR_ARG;
+    if (!h->last_kernel) return fail(h, SDDP_ERR_ARG, "no solve launch yet");
+    hipFuncAttributes at;
+    HIP_TRY(h, hipFuncGetAttributes(&at, h->last_kernel));
+    if (vgprs) *vgprs = at.numRegs;
+    if (scratch_bytes_per_lane) *scratch_bytes_per_lane = int(at.localSizeBytes);
+    if (lds_bytes) *lds_bytes = h->last_lds + int(at.sharedSizeBytes);
+    if (workgroups_per_cu) *workgroups_per_cu = h->last_per_cu;
+    return SDDP_OK;
+}
+
 int sddp_synchronize(sddp_handle* h) {
     if (!h) return SDDP_ERR_ARG;
     HIP_TRY(h, hipStreamSynchronize(h->stream));

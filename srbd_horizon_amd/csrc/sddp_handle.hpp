@@ -85,7 +85,9 @@ struct sddp_handle {
     struct KInfo { const void* fn = nullptr; int slots = 0; };
     KInfo kinfo[2];                 // per kernel build: dynamic-LDS attribute set, resident workgroups on this device
     int last_grid = 0, last_queued = 0;
-    int last_build = 0;             // waves_per_simd of the kernel build the last solve launch ran (sddp_queue_info2)
+    int last_build = 0;             // waves_per_simd of the kernel build the last solve launch ran (sddp_kernel_info)
+    const void* last_kernel = nullptr;   // ... and that kernel, its dynamic LDS bytes and its workgroups per CU (sddp_kernel_resources)
+    int last_lds = 0, last_per_cu = 0;
     double* box_dev = nullptr;      // lower[64] | upper[64] of the bound barrier (barrier builds)
     double* first_dev = nullptr;    // [B][nu + nx + 3] packed first knots of sddp_solve_resident_first, and its pinned host image
     double* first_pin = nullptr;

@@ -116,6 +116,9 @@ int launch_solve(sddp_handle* h, SolveArgs a, int first, int count) {
     }
     h->last_grid = grid; h->last_queued = count > grid ? count : 0;
     h->last_build = wps;
+    h->last_kernel = reinterpret_cast<const void*>(kern);
+    h->last_lds = int(lds);
+    h->last_per_cu = slots / std::max(1, h->cus);
     h->gains_by_instance = (count <= grid && first == 0);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, h->stream, a);
     HIP_TRY(h, hipGetLastError());

@@ -268,8 +268,13 @@ class DdpEngine:
         w, b, nm = C.c_int(), C.c_int(), C.c_char_p()
         self._chk(self.lib.sddp_kernel_info(self.h, C.byref(w), C.byref(b), C.byref(nm)))
         base = "solve_kernel_mw" if w.value == 4 else "solve_kernel"
-        return dict(kernel=f"{base}{'_w2' if b.value == 2 else ''}<{nm.value.decode()}>", wavefronts_per_instance=w.value,
-                    waves_per_simd=b.value)
+        out = dict(kernel=f"{base}{'_w2' if b.value == 2 else ''}<{nm.value.decode()}>", wavefronts_per_instance=w.value,
+                   waves_per_simd=b.value)
+        v, sc, lds, per = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        if self.lib.sddp_kernel_resources(self.h, C.byref(v), C.byref(sc), C.byref(lds), C.byref(per)) == 0:
+            out["resources"] = dict(vgprs=v.value, scratch_bytes_per_lane=sc.value, lds_bytes_per_workgroup=lds.value,
+                                    workgroups_per_cu=per.value)
+        return out
 
 
 def eval_knots(model: str, N: int, k, x, u, p, consts: dict | None = None):
