@@ -2,7 +2,7 @@
 """The reference's example loops without ROS: python/dsrbd_example.py:82-185 (model srbd37, the default) and
 python/dlip_example.py:89-160 (model lip30), or the reduced metric model (srbd13), on the MI355X engine.
 
-    python examples/mpc_loop.py [--model srbd37|lip30|srbd13] [--ticks 200] [--motion walking|standing|jumping]
+    python examples/mpc_loop.py [--model srbd37|srbd61|lip30|srbd13] [--ticks 200] [--motion walking|standing|jumping]
                                 [--vx 1.0] [--vy 0.0] [--host-shift] [--barrier W]
 
 Prints per-tick solve time (what the reference publishes on `solution_time`, dsrbd_example.py:134-136), iterations, and the
@@ -20,7 +20,7 @@ from srbd_horizon_amd.mpc import MpcLoop  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="srbd37", choices=["srbd37", "lip30", "srbd13"])
+    ap.add_argument("--model", default="srbd37", choices=["srbd37", "srbd61", "lip30", "srbd13"])
     ap.add_argument("--ns", type=int, default=None, help="knots (default 20 as the examples; 30 for srbd13)")
     ap.add_argument("--ticks", type=int, default=200)
     ap.add_argument("--motion", default="walking", choices=["walking", "standing", "jumping"])
