@@ -249,6 +249,7 @@ __device__ void sweep_tables_mw(const DevConsts& c, double* s, int tid) {
 template <class M>
 __device__ void mw_const_block(const DevConsts& c, int tid, double (&qconst)[LdsMW<M>::TQ][3][3]) {
     using L = LdsMW<M>;
+    if constexpr (L::TQ > 1) return;        // several blocks per thread: the constant rows are a sparse pass in the sweep (add_const_rows)
 #pragma unroll
     for (int tq = 0; tq < L::TQ; ++tq) {
         const int t = tid + tq * kThreadsMW;
@@ -537,10 +538,10 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) acc[i][j] = qacc[tq][i][j];
-                if constexpr (ND > 0) dot_block<3, 3, L::DG8>(s + L::GC + a0 * L::SGC, L::SGC, s + L::FC + b0 * SC, SC, acc);
+                if constexpr (ND > 0) dot_block<3, 3, L::DG8, (TQ > 1 ? 1 : 2)>(s + L::GC + a0 * L::SGC, L::SGC, s + L::FC + b0 * SC, SC, acc);
             }
-            dot_block<3, 3, SC>(s + L::FC + a0 * SC, SC, s + L::WC + b0 * SC, SC, acc);
-            if (NEV < NE) {
+            dot_block<3, 3, SC, (TQ > 1 ? 1 : 2)>(s + L::FC + a0 * SC, SC, s + L::WC + b0 * SC, SC, acc);
+            if (NEV < NE && TQ == 1) {      // (several blocks per thread: the constant rows are a sparse pass after the barrier)
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -580,6 +581,8 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         }
         __syncthreads();
         SDDP_TICK(14)
+        constexpr bool kConstPass = TQ > 1 && NEV < NE;     // the constant extra rows as a sparse pass (entries disjoint from the torque term's)
+        if (kConstPass) M::add_const_rows(c, qm, tid, kThreadsMW);
         if (theta != 0.0) {   // exact second-order torque term (uniform switch)
             if (M::NSO2T) {   // full second-order builds: the per-knot factors of the contraction first
                 M::so2_prepare(c, s + L::REC, s + L::VP, s + L::REC + L::SO2T, tid, kThreadsMW);
@@ -588,7 +591,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             M::add_second_order(c, s + L::REC, s + L::VP, qm, theta, tid, kThreadsMW, s + L::REC + L::SO2T,
                                 reinterpret_cast<const int*>(s + L::KI) + L::SO2L);
             __syncthreads();
-        }
+        } else if (kConstPass) __syncthreads();
         if (M::BAR) {         // friction-cone barrier builds: its Hessian blocks on the force-force diagonal of Q
             M::add_barrier(s + L::REC, qm, tid, kThreadsMW, M::SO2 ? theta : 0.0);
             __syncthreads();

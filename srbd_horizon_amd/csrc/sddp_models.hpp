@@ -1198,6 +1198,35 @@ struct SrbdModel {
         }
     }
 
+    // The constant extra rows' share of Q (rows m >= NEV: rddot and, with contact states, the relative-velocity penalties; weights
+    // lam_stage) as a SPARSE pass, one thread per non-zero element of the lower triangle, for kernels that cannot afford to keep it
+    // as a per-thread constant block (the 4-wavefront kernel with several Q blocks per thread: srbd61).  rddot_a = inv_ms sum_i f_i,a:
+    // 2 gq inv_ms^2 on every (f_i,a ; f_j,a); relative velocity, component e: 2 w_pen (pairs of contact i) on the diagonal of cdot_i,e,
+    // -2 w_pen on (cdot_lead,e ; cdot_follower,e) (prb.py:166-170).  Disjoint from the entries add_second_order touches (f x r, f x c).
+    static constexpr int NFF = NC * (NC + 1) / 2, NCONST = 3 * NFF + (CS ? 2 * (NC + NRV) : 0);
+    template <class QM>
+    __device__ __forceinline__ static void add_const_rows(const DevConsts& c, QM Q, int tid, int nthreads) {
+        for (int e = tid; e < NCONST; e += nthreads) {
+            int row, col;
+            double val;
+            if (e < 3 * NFF) {
+                const int ax = e / NFF, t = e % NFF;
+                int i = 0;
+                while ((i + 1) * (i + 2) / 2 <= t) ++i;
+                const int j = t - i * (i + 1) / 2;
+                row = NX + uf(i) + ax; col = NX + uf(j) + ax;
+                val = 2 * c.gq * c.inv_ms * c.inv_ms;
+            } else {
+                const int e2 = e - 3 * NFF, comp = e2 / (NC + NRV), t = e2 % (NC + NRV);
+                if (t < NC) { row = col = XCD + 3 * t + comp; val = 2 * c.w_pen * double(rv_count(t)); }
+                else { const int q = t - NC; row = XCD + 3 * rv_b(q) + comp; col = XCD + 3 * rv_a(q) + comp; val = -2 * c.w_pen; }
+            }
+            const double q0 = Q.at(row, col) + val;
+            Q.at(row, col) = q0;
+            if (row != col) Q.at(col, row) = q0;
+        }
+    }
+
     // BAR builds: the barrier's Gauss-Newton Hessian blocks (3x3 per contact force, from the record) added to Quu
     // ... and the diagonal of the bound barrier; so2_theta (SO2 builds: theta of this sweep, else 0): its exact Hessian is twice the
     // Gauss-Newton one, like the friction barrier's (whose share is added in add_second_order)
@@ -1226,6 +1255,7 @@ struct LipModel {
     static constexpr int NC = 4;
     static constexpr bool BAR = false;
     template <class QM> __device__ __forceinline__ static void add_barrier(const double*, QM, int, int, double = 0.0) {}
+    template <class QM> __device__ __forceinline__ static void add_const_rows(const DevConsts&, QM, int, int) {}   // (one Q block per thread: unused)
     static constexpr int NX = 30, NU = 15, NZ = 45, NP = 11;
     static constexpr int XR = 0, XC = 3, XRD = 15, XCD = 18;
     static constexpr int REC_G = 0, NREC = NZ, NSO2T = 0, NSO2L = 0;
