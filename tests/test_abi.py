@@ -60,3 +60,23 @@ def test_no_cpu_fallback_without_device(lib):
     from srbd_horizon_amd.engine import DdpEngine
     with pytest.raises(RuntimeError):
         DdpEngine("srbd13", 30, 1)
+
+
+def build_c_host(tmp_path):
+    """examples/c_abi_solve.c: a plain-C host on include/sddp.h (gcc, no Python, no torch in the process)"""
+    import subprocess
+    exe = str(tmp_path / "c_abi_solve")
+    libdir = os.path.join(ROOT, "srbd_horizon_amd")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_solve.c"),
+                    "-o", exe, "-L" + libdir, "-lsddp_hip", "-Wl,-rpath," + libdir, "-lm"], check=True, capture_output=True)
+    return exe
+
+
+def test_c_host_program_links_against_the_abi_and_fails_loudly_without_a_device(lib, tmp_path):
+    import subprocess
+    import torch
+    exe = build_c_host(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: tests/test_gpu_shim.py runs the program")
+    r = subprocess.run([exe, "4"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device" in r.stderr

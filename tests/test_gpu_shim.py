@@ -77,3 +77,39 @@ def test_costs_changed_through_the_facade_reach_the_kernel():
 def pb_term(key, ckey, gain):
     from srbd_horizon_amd.problem import Term
     return Term(key, ckey, gain)
+
+
+def test_c_host_program_gets_the_same_solve(tmp_path):
+    """examples/c_abi_solve.c (plain C on include/sddp.h, no Python in its process) against the ctypes path and the numpy oracle on
+    the same problem: one standing srbd13 robot, cold solve, then warm-started ticks on device-resident data."""
+    import json
+    import subprocess
+    from oracle import ddp as oddp, models as omodels
+    from srbd_horizon_amd import _lib
+    from tests.test_abi import build_c_host
+    _lib.build()
+    out = json.loads(subprocess.run([build_c_host(tmp_path), "12"], check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1])
+    N = 30
+    c = _lib.default_consts()
+    feet = np.array(list(c.feet)).reshape(4, 3)
+    x0 = np.zeros(13); x0[0], x0[1], x0[2], x0[6], x0[7] = 0.01, -0.005, c.com[2] + 0.01, 1.0, 0.02
+    P = np.zeros((N + 1, 19)); P[:, 6] = 1e2; P[:, 10] = 1.0
+    P[:, 11:14] = 0.5 * (feet[0] + feet[1]); P[:, 14:17] = 0.5 * (feet[2] + feet[3]); P[:, 17:19] = 1.0
+    xs = np.repeat(x0[None], N + 1, axis=0)
+    us = np.zeros((N, 6)); us[:, 2] = us[:, 5] = c.m * 9.81 / c.force_scaling / 2.0
+    opts = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
+    r = oddp.solve(omodels.make_model("srbd13"), x0, P, xs, us, oddp.DdpOptions(**opts))
+    assert out["cold_iters"] == r.iters and out["cold_converged"] == int(r.converged)
+    assert abs(out["cold_cost"] - r.cost) <= 1e-9 * abs(r.cost)
+    eng = DdpEngine("srbd13", N, 1, opts=opts)
+    eng.set_initial_state(x0[None]); eng.set_x_warmstart(xs[None]); eng.set_u_warmstart(us[None])
+    x, u = eng.solve(P[None])
+    assert eng.stats["cost"][0] == out["cold_cost"]                       # the same library, the same bits
+    eng.set_params(P[None])
+    for _ in range(12):
+        eng.advance(P[None, -1], x[:, 1])
+        x, u = eng.solve_resident()
+    assert eng.stats["cost"][0] == out["tick_cost"] and int(eng.stats["iters"][0]) == out["tick_iters"]
+    np.testing.assert_array_equal(u[0, 0], np.array(out["u0"]))
+    assert out["tick_converged"] == 1 and 0.0 < out["ms_per_tick"] < 50.0
+    print("C host: ms per warm-started tick", out["ms_per_tick"], "iterations", out["tick_iters"])
