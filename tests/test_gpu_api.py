@@ -216,7 +216,7 @@ def test_model_step_is_the_dynamics_of_the_knot_evaluation(model, N):
         eng.model_step(x, u, batch["params"][:, N], N)
 
 
-@pytest.mark.parametrize("model,ns", [("srbd13", 30), ("srbd37", 20), ("lip30", 20)])
+@pytest.mark.parametrize("model,ns", [("srbd13", 30), ("srbd37", 20), ("lip30", 20), ("srbd61", 20)])
 def test_device_resident_receding_horizon_equals_the_host_shift(model, ns):
     """sddp_set_params / sddp_advance / sddp_solve_resident: shifting the parameter tensor and the warm
     start on the device gives the same ticks as shifting them on the host and passing them through sddp_solve."""
