@@ -17,7 +17,7 @@ sc = np.zeros((B, 24))
 fn = eng.lib.sddp_debug_read_scal; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p]
 assert fn(eng.h, sc.ctypes.data_as(C.c_void_p)) == 0
 it = eng.stats["iters"]; ro = eng.stats["rollouts"]
-names = ["derivs", "bw.stage", "bw.expand+vp", "bw.W=VxxF", "bw.Q=H+FtW", "bw.solve", "bw.Vupd+gains", "-", "rollout", "other"]
+names = ["derivs", "bw.stage", "bw.expand+vp", "bw.W (W-free: GC|WC + gathers)", "bw.Q=H+FtW", "bw.solve", "bw.Vupd+gains", "-", "rollout", "other"]
 names += ["ro.feedback", "ro.close-knot", "ro.step", "bw.Q.blocks(mw)", "bw.Q.qv+barrier(mw)", "s15", "gj.load", "gj.owner", "gj.syncwait", "gj.update(+last)", "gj.publish", "s21","s22","s23"]
 tot = sc[:, :24].sum(axis=1)
 print("kernel ms", eng.last_kernel_ms(), "mean iters", it.mean(), "mean rollouts", ro.mean())

@@ -1,23 +1,25 @@
-// sddp_kernels_mw.hpp -- the same DDP iteration as sddp_kernels.hpp for the LARGE models (srbd37: 37x37 / 61x61 tiles,
-// lip30), mapped on one 256-thread workgroup (4 wavefronts, one per SIMD of a CU) per MPC instance.
+// sddp_kernels_mw.hpp -- the same DDP iteration as sddp_kernels.hpp for the LARGE models (srbd37: 37x37 / 61x61 tiles, srbd61:
+// 61x61 / 109x109, lip30), mapped on one 256-thread workgroup (4 wavefronts, one per SIMD of a CU) per MPC instance.
 //
-//   * Tile phases of the Riccati sweep: one THREAD per 3x3 / 3x4 / 2x2 register block of the output tile, operands read
-//     with ds_read_b128 from rows whose stride is == 2 (mod 4) doubles, so that the rows of a block column fall on 16
-//     distinct 16-byte LDS slots (MI355X_MICROARCH.md, LDS: b128 reads conflict per 16-lane group on (addr/4) mod 64).
-//   * Quu solve: block Gauss-Jordan across the 4 waves.  Lane j of every wave owns column j of [Quu + mu I | Qu | Qux];
-//     wave w owns rows [w RPW, (w+1) RPW).  Step b: wave b reduces its own rows (pivot column by v_readlane), publishes them
-//     in LDS, the other waves eliminate their rows against them: 4 hand-offs per knot instead of NU.
+//   * Tile phases of the Riccati sweep: one THREAD per 3x3 block of Q / 2x2 block of Vxx (srbd61: three / two blocks per thread),
+//     operands read with ds_read_b128 from rows whose stride is == 2 (mod 4) doubles, so that the rows of a block column fall on
+//     16 distinct 16-byte LDS slots (MI355X_MICROARCH.md, LDS: b128 reads conflict per 16-lane group on (addr/4) mod 64).
+//   * The products run over the column sparsity of [fx fu]; the SRBD models do so without the dense (Vxx F)^T tile ("W-free":
+//     LdsMW, mw_wfree).
+//   * Quu solve: block Gauss-Jordan across the 4 waves.  A lane owns column lane (+ 64 for the second one at srbd61) of
+//     [Quu + mu I | Qu | Qux]; wave w owns rows [w RPW, (w+1) RPW).  Step b: wave b reduces its own rows (pivot column by
+//     v_readlane), publishes them in LDS, the other waves eliminate their rows against them: 4 hand-offs per knot instead of NU.
 //   * Forward pass (line search, one lane per step length): the feedback product u = u_k + alpha k + K (x - x_k) is split
 //     by rows over the 4 waves with the knot's gains staged in LDS (broadcast reads) and the per-lane vectors kept as LDS
 //     columns; the scalar model step runs in wave 0 while the other waves stage the next knot's gains.
 //   * Every wave keeps an identical copy of the scalar solver state (cost, merit weight, regularisation, counters); values
 //     produced by one wave only reach the others through the control words CTL[..] behind a workgroup barrier.
 //
-//   * LDS: 75.7 KB (srbd37) / 45 KB (lip30) per instance, so that two workgroups share a CU (solve_kernel_mw_w2); Q has no
-//     tile of its own -- see LdsMW.
+//   * LDS per instance: 50.9 KB (srbd37; two workgroups share a CU: solve_kernel_mw_w2), 32.0 KB (lip30), 145.3 KB (srbd61, one
+//     per CU); Q has no tile of its own -- see LdsMW.  tests/test_lds_budget.py pins these.
 //
 // These models need > 40 KB of LDS per instance (<= 2 workgroups per CU at 256 registers), so the 4 waves do not fight the
-// register budget that rules this mapping out for srbd13 at four instances per CU (experiment log).
+// register budget that rules this mapping out for srbd13 at four instances per CU (profiles/experiment_log_r01_r03.md).
 // Same device model code, same arithmetic up to summation order, same parity tests as the single-wavefront kernel.
 #pragma once
 #include "sddp_kernels.hpp"
