@@ -372,15 +372,34 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         if (has_gap && lane < NX) r_d = dft[k * NX + lane];
     };
     if (lane < NXP) s[L::DK + lane] = 0.0;
+    // gains of knot kk, LDS (KF | K^T, as the solve phase left them) -> HBM/L2: word e of the knot's record = kff[e] for e < NU, else
+    // K[i][c] = KT[c][i] with (i, c) = divmod(e - NU, NX); whole-wave contiguous stores
+    constexpr int NGW = NU * (NX + 1), RGW = (NGW + kWave - 1) / kWave;
+    int g_src[RGW];
+#pragma unroll
+    for (int t = 0; t < RGW; ++t) {
+        const int e = lane + t * kWave, ec = e < NGW ? e : 0;
+        g_src[t] = ec < NU ? L::KF + ec : L::KT + ((ec - NU) % NX) * NUP + (ec - NU) / NX;
+    }
+    auto store_gains = [&](int kk) {
+        double* gk = gains + size_t(kk) * NGW;
+        double v[RGW];
+#pragma unroll
+        for (int t = 0; t < RGW; ++t) v[t] = s[g_src[t]];
+#pragma unroll
+        for (int t = 0; t < RGW; ++t)
+            if (lane + t * kWave < NGW) gk[lane + t * kWave] = v[t];
+    };
     fetch(N - 1);
     for (int k = N - 1; k >= 0; --k) {
-        // ---- stage this knot from the prefetch registers; start the next knot's loads
+        // ---- stage this knot from the prefetch registers; start the next knot's loads; then the previous knot's gains go out
 #pragma unroll
         for (int t = 0; t + 1 < RREC; ++t) s[L::REC + lane + t * kWave] = r_rec[t];
         if (t_on) s[t_dst] = r_rec[RREC - 1];
         if (!MERGE_P && lane < NP) s[L::PK + lane] = r_p;
         if (has_gap && lane < NX) s[L::DK + lane] = r_d;
         if (k > 0) fetch(k - 1);
+        if (k < N - 1) store_gains(k + 1);
         wave_sync();
         SDDP_TICK(1)
         const double state = k >= 1 ? 1.0 : 0.0;
@@ -562,17 +581,14 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
 #pragma unroll
             for (int i = 0; i < NU; ++i) a[i] = (i == p) ? t : fma(-pv[i], t, a[i]);
         }
-        // a = Quu^-1 * column ; publish kff and K^T (negated) in LDS, and the gains to HBM/L2 straight from the registers:
-        // kff (NU) then K (NU x NX) row-major; row i of K is one contiguous store of the NX column lanes
+        // a = Quu^-1 * column ; publish kff and K^T (negated) in LDS.  The copy to HBM/L2 (kff (NU) then K (NU x NX) row-major) is
+        // made from there one knot later, behind the next staging wait (store_gains): a store in flight makes every wait for a
+        // prefetched load a full vmcnt(0) (gfx9 counts loads and stores in one counter and returns them out of order with respect
+        // to each other), so stores issued at the end of a knot were waited for at the start of the next
         if (lane >= NU && lane < NCOL) {
             double* dst = lane == NU ? s + L::KF : s + L::KT + (lane - NU - 1) * NUP;            // KF follows KT: one region
-            double* gk = gains + size_t(k) * (NU * (NX + 1)) + (lane == NU ? 0 : NU + (lane - NU - 1));
-            const int gstride = lane == NU ? 1 : NX;
 #pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                dst[i] = -a[i];
-                gk[i * gstride] = -a[i];
-            }
+            for (int i = 0; i < NU; ++i) dst[i] = -a[i];
         }
         // kff broadcast from lane NU; then ONE dot product per lane with the column it loaded gives both
         //   lane NU:        kff . Qu           -> dV1 (dV2 = 1/2 kff^T Quu kff = -1/2 dV1 exactly, not accumulated separately)
@@ -621,6 +637,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         wave_sync();
         SDDP_TICK(6)
     }
+    store_gains(0);
     G1 = wave_sum(G1);
     G2 = wave_sum(G2);
     return ok;

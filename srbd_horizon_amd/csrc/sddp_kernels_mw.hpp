@@ -337,9 +337,17 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
     double r_stage[RS];
 #pragma unroll
     for (int t = 0; t < RS; ++t) r_stage[t] = stage_word(N - 1, tid + t * kThreadsMW);
+    // gains of knot kk, LDS (KF | K^T as the solve left them; intact until the next knot's W / GC | WC phase) -> HBM/L2, whole-wave
+    // contiguous stores one knot later: kff (NU) then K (NU x NX) row-major.  A store in flight turns every wait for a prefetched
+    // load into a full vmcnt(0) (one counter for loads and stores on gfx9), so they are issued right after such a wait, not before it
+    constexpr int NGW = NU * (NX + 1);
+    auto store_gains = [&](int kk) {
+        double* gk = gains + size_t(kk) * NGW;
+        for (int e = tid; e < NGW; e += kThreadsMW) gk[e] = e < NU ? s[L::KF + e] : s[L::KT + ((e - NU) % NX) * SK + (e - NU) / NX];
+    };
     __syncthreads();
     for (int k = N - 1; k >= 0; --k) {
-        // ---- stage this knot from the prefetch registers; start the next knot's loads
+        // ---- stage this knot from the prefetch registers; start the next knot's loads; the previous knot's gains go out
 #pragma unroll
         for (int t = 0; t < RS; ++t) {
             const int w = tid + t * kThreadsMW;
@@ -351,6 +359,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
 #pragma unroll
             for (int t = 0; t < RS; ++t) r_stage[t] = stage_word(k - 1, tid + t * kThreadsMW);
         }
+        if (k < N - 1) store_gains(k + 1);
         __syncthreads();
         SDDP_TICK(1)
         const double state = k >= 1 ? 1.0 : 0.0;
@@ -710,20 +719,16 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
             SDDP_TICK(19)
             // a = Quu^-1 * column ; publish kff and K^T (negated) ; dV1 += kff . Qu
             double dv = 0.0;
-            // also the gains to HBM/L2 straight from the registers: kff (NU) then K (NU x NX) row-major; row i of K is one
-            // contiguous store of the NX column lanes
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) {
                 const int col = lane + kWave * cc;
                 double* dst = col == NU ? s + L::KF : s + L::KT + (col - NU - 1) * SK;
-                double* gk = gains + size_t(k) * (NU * (NX + 1)) + (col == NU ? 0 : NU + (col - NU - 1));
-                const int gstride = col == NU ? 1 : NX;
                 const bool pub = col >= NU && col < NCOL;
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
                     const int i = wave * RPW + r;
                     if (i < NU) {
-                        if (pub) { dst[i] = -a[r][cc]; gk[i * gstride] = -a[r][cc]; }
+                        if (pub) dst[i] = -a[r][cc];          // (the copy to HBM/L2: store_gains, one knot later)
                         if (cc == 0) dv += -a[r][0] * qu_save[r];
                     }
                 }
@@ -782,6 +787,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
         __syncthreads();
         SDDP_TICK(6)
     }
+    store_gains(0);
     // ---- combine the per-wave partial sums (same values, same order in every thread)
     if (wave == kLast) {
         g1_acc = wave_sum(g1_acc);
@@ -971,8 +977,8 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
             if (OPEN_LOOP) J += M::step(c, X, U, sb + L::SB_P, k, X);
             else J += M::step(c, X, U, sb + L::SB_P, k, LdsColClose{X.p, sb + L::SB_D, oma});
         } else {
+            if (k + 1 < N) stage_knot(k + 1);        // (loads first: a store in flight would be waited for with them -- vmcnt counts both)
             if (tid - kWave < NU) un[k * NU + tid - kWave] = s[L::RO_U + (tid - kWave) * kWave + store_lane];
-            if (k + 1 < N) stage_knot(k + 1);
         }
         SDDP_TICK(12)
     }
