@@ -176,6 +176,10 @@ int  sddp_kernel_info(sddp_handle* h, int* wavefronts_per_instance, int* last_wa
  * lane, scratch (spill) bytes per lane, LDS bytes per workgroup (static + dynamic), and how many of its workgroups the device keeps
  * resident per CU (the occupancy query the queue's slot count comes from).  Any pointer may be NULL. */
 int  sddp_kernel_resources(sddp_handle* h, int* vgprs, int* scratch_bytes_per_lane, int* lds_bytes, int* workgroups_per_cu);
+/* Diagnostic for the parity tests: fills the LDS of the device's CUs with NaNs (8 short workgroups per CU, each owning the CU's
+ * whole LDS) and waits.  A kernel finds in LDS what the previous one left; after this call a word read before it is written shows
+ * up as a NaN in the result instead of passing on a lucky leftover.  Not part of any solve path. */
+int  sddp_debug_poison_lds(sddp_handle* h);
 /* results of the last device solve (x, u, stats of the whole batch) to host pointers; waits for the stream */
 int  sddp_fetch(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats /*[B] or NULL*/);
 /* which: 0 xs [B][N+1][nx], 1 us [B][N][nu], 2 stats [B] (sddp_stats), 3 gains [slots][N][nu*(nx+1)], 4 x0 [B][nx],

@@ -87,6 +87,7 @@ SYMBOLS = {
     "sddp_synchronize": (C.c_int, [_vp]),
     "sddp_kernel_info": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_char_p)]),
     "sddp_kernel_resources": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
+    "sddp_debug_poison_lds": (C.c_int, [_vp]),
     "sddp_device_ptr": (C.c_int, [_vp, C.c_int, _P(_vp), _P(C.c_longlong)]),
     "sddp_last_kernel_ms": (C.c_int, [_vp, _P(C.c_double)]),
     "sddp_enable_timing": (C.c_int, [_vp, C.c_int]),

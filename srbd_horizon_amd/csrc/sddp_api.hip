@@ -455,6 +455,20 @@ int sddp_kernel_resources(sddp_handle* h, int* vgprs, int* scratch_bytes_per_lan
     return SDDP_OK;
 }
 
+int sddp_debug_poison_lds(sddp_handle* h) {
+    if (!h) return SDDP_ERR_ARG;
+    int dev = 0;
+    hipDeviceProp_t pr;
+    HIP_TRY(h, hipGetDevice(&dev));
+    HIP_TRY(h, hipGetDeviceProperties(&pr, dev));
+    const int bytes = int(pr.maxSharedMemoryPerMultiProcessor);            // 160 KB on gfx950: one such workgroup per CU at a time
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(8 * pr.multiProcessorCount), dim3(256), bytes, h->stream, bytes / 8, h->hist);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDDP_OK;
+}
+
 int sddp_synchronize(sddp_handle* h) {
     if (!h) return SDDP_ERR_ARG;
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -50,6 +50,15 @@ __global__ __launch_bounds__(256) void first_knot_kernel(int N, int B, int nx, i
     }
 }
 
+// diagnostic (sddp_debug_poison_lds): a workgroup that owns a CU's whole LDS and fills it with NaNs.  What a kernel finds in LDS
+// is whatever the previous one left there; after this one a read of a word the kernel never wrote cannot pass a parity test.
+__global__ __launch_bounds__(256) void poison_lds_kernel(int words, int* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    for (int e = threadIdx.x; e < words; e += 256) lds_all[e] = __builtin_nan("");
+    __syncthreads();
+    if (lds_all[threadIdx.x] == 1.0) *sink = 1;          // (never true: keeps the stores)
+}
+
 constexpr int kAdvanceWords = 4096;   // longest array advance_kernel shifts in one workgroup: (N+1) * max(nx, np) words
 
 // receding-horizon tick on the device: shift parameters and warm start by one knot (one workgroup per instance; every element

@@ -823,28 +823,55 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
     const LdsCol X{s + L::RO_X + lane}, U{s + L::RO_U + lane};
     double* kf = s + L::RO_G;                                      // staged gains of one knot: kff [NU]
     double* kb = s + L::RO_K;                                      //                           K [NU][SG]
-    auto stage_knot = [&](int k) {                                 // waves 1..3
-        double* sb = s + L::RO_S + (k & 1) * L::SB_N;
+    // Staging of a knot's operands by waves 1..3 (stager thread se = tid - 64): every load of the knot first, into registers, then
+    // the LDS writes -- one memory round trip per knot.  (A loop of load / wait / LDS store pairs pays one per trip: 5 for the
+    // gains of srbd37 plus the operand word, each behind reloads of spilled addresses in the two-per-SIMD build.)  Where the
+    // registers allow (kEarlyFetch) the loads are issued before the feedback phase and land during it.
+    constexpr int TS = (NSB + kStagers - 1) / kStagers, TG = (NG + kStagers - 1) / kStagers;
+    constexpr bool kEarlyFetch = false;
+    const int se = tid - kWave;
+    double r_s[TS], r_g[TG];
+    auto fetch_knot = [&](int k) {
         if (!OPEN_LOOP) {
             const double* gk = gains + size_t(k) * NG;
-            for (int e = tid - kWave; e < NG; e += kStagers) {
-                const double v = gk[e];
-                if (e < NU) kf[e] = v;
-                else { const int i = (e - NU) / NX, j = (e - NU) % NX; kb[i * SG + j] = v; }
+#pragma unroll
+            for (int t = 0; t < TG; ++t) { const int e = se + t * kStagers; r_g[t] = e < NG ? gk[e] : 0.0; }
+        }
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+            const int e = se + t * kStagers;
+            const double* src = e < NX ? xs + k * NX + e : e < NX + NU ? us + k * NU + (e - NX)
+                              : e < 2 * NX + NU ? dft + k * NX + (e - NX - NU) : P + k * NP + (e - 2 * NX - NU);
+            r_s[t] = e < NSB ? *src : 0.0;
+        }
+    };
+    auto put_knot = [&](int k) {
+        double* sb = s + L::RO_S + (k & 1) * L::SB_N;
+        if (!OPEN_LOOP) {
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const int e = se + t * kStagers;
+                if (e < NG) {
+                    if (e < NU) kf[e] = r_g[t];
+                    else { const int i = (e - NU) / NX, j = (e - NU) % NX; kb[i * SG + j] = r_g[t]; }
+                }
             }
         }
-        for (int e = tid - kWave; e < NSB; e += kStagers) {
-            if (e < NX) sb[L::SB_X + e] = xs[k * NX + e];
-            else if (e < NX + NU) sb[L::SB_U + e - NX] = us[k * NU + e - NX];
-            else if (e < 2 * NX + NU) sb[L::SB_D + e - NX - NU] = dft[k * NX + e - NX - NU];
-            else sb[L::SB_P + e - 2 * NX - NU] = P[k * NP + e - 2 * NX - NU];
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+            const int e = se + t * kStagers;
+            if (e < NSB) sb[e < NX ? L::SB_X + e : e < NX + NU ? L::SB_U + e - NX : e < 2 * NX + NU ? L::SB_D + e - NX - NU : L::SB_P + e - 2 * NX - NU] = r_s[t];
         }
     };
     __syncthreads();                                               // the tiles this pass aliases are no longer read
     if (wave == 0) {
         for (int i = 0; i < NX; ++i) X[i] = x0[i];
     } else {
-        stage_knot(0);
+        // the pad column of the staged gain rows (odd nx) is read by the wide feedback product against a zero of x - x_k: it has to
+        // be finite, and a kernel that starts with this pass (forward_kernel_mw) finds whatever the LDS held before
+        if (SG > NX && se < NU) kb[se * SG + NX] = 0.0;
+        fetch_knot(0);
+        put_knot(0);
     }
     double J = 0.0;
     const double oma = 1.0 - alpha;
@@ -854,6 +881,7 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
         // (x_k is in the X columns: x0, or written by the step of knot k - 1, which also closed that knot -- LdsColClose)
         __syncthreads();
         SDDP_TICK(11)
+        if (kEarlyFetch && wave != 0 && k + 1 < N) fetch_knot(k + 1);
         // ---- B: every wave computes UPW rows of u = u_k + alpha kff + K (x - x_k)
         if (wave == kWavesMW - 1 && lane < NX) xn[k * NX + lane] = s[L::RO_X + lane * kWave + store_lane];
         if constexpr (NX <= 40) {
@@ -977,7 +1005,10 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
             if (OPEN_LOOP) J += M::step(c, X, U, sb + L::SB_P, k, X);
             else J += M::step(c, X, U, sb + L::SB_P, k, LdsColClose{X.p, sb + L::SB_D, oma});
         } else {
-            if (k + 1 < N) stage_knot(k + 1);        // (loads first: a store in flight would be waited for with them -- vmcnt counts both)
+            if (k + 1 < N) {                         // (loads before the store below: a store in flight would be waited for with them -- vmcnt counts both)
+                if (!kEarlyFetch) fetch_knot(k + 1);
+                put_knot(k + 1);
+            }
             if (tid - kWave < NU) un[k * NU + tid - kWave] = s[L::RO_U + (tid - kWave) * kWave + store_lane];
         }
         SDDP_TICK(12)

@@ -261,6 +261,11 @@ class DdpEngine:
         self._chk(self.lib.sddp_queue_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def poison_lds(self):
+        """Diagnostic (parity tests): fill the LDS of every CU with NaNs, so the next launch cannot pass on what an earlier kernel
+        happened to leave in a word it reads before writing."""
+        self._chk(self.lib.sddp_debug_poison_lds(self.h))
+
     def kernel_info(self):
         """-> dict(kernel, wavefronts_per_instance, waves_per_simd): the solve kernel the LAST launch of this handle ran
         (``solve_kernel[_w2]<model>`` on one wavefront per instance or ``solve_kernel_mw[_w2]<model>`` on four; ``_w2`` = the

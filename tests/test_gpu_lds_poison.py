@@ -1,0 +1,50 @@
+"""No kernel of the library may read an LDS word before writing it: a launch finds in LDS whatever the previous kernel on that CU
+left behind, so such a read passes or fails by the order the tests ran in (round 4: the forward-pass kernel of srbd61 multiplied
+the never-written pad column of its staged gain rows by a zero of x - x_k -- a NaN when the leftover was one).
+sddp_debug_poison_lds fills every CU's LDS with NaNs; each single-phase kernel and the fused solve of every model then has to return
+what it returns on clean LDS, bit for bit."""
+import numpy as np
+import pytest
+
+from srbd_horizon_amd import workload
+from srbd_horizon_amd.engine import DdpEngine
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(eng, batch, xs, us, poison):
+    out = []
+    for phase in ("backward", "forward", "solve"):
+        eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(xs); eng.set_u_warmstart(us)
+        if phase == "forward":                       # the forward pass applies the gains the sweep left in the slots' buffers
+            eng.backward(batch["params"], mu=0.0)
+        if poison:
+            eng.poison_lds()
+        if phase == "backward":
+            kff, K, scal = eng.backward(batch["params"], mu=0.0)
+            out += [kff.copy(), K.copy(), scal[:, :5].copy()]
+        elif phase == "forward":
+            x, u, J = eng.forward(batch["params"], 0.25)
+            out += [x, u, J]
+        else:
+            x, u = eng.solve(batch["params"])
+            out += [x, u, eng.stats["cost"].copy(), eng.stats["iters"].copy()]
+    return out
+
+
+@pytest.mark.parametrize("model,N,wps", [("srbd13", 30, 1), ("srbd13", 30, 2), ("srbd37", 20, 1), ("srbd37", 20, 2), ("lip30", 20, 2),
+                                         ("srbd61", 20, 1)])
+def test_results_do_not_depend_on_what_the_lds_held(model, N, wps):
+    seeds = [0, 3, 11]
+    batch = workload.make_batch(model, N, seeds)
+    rng = np.random.default_rng(2)
+    xs = batch["xs"] + 1e-3 * rng.standard_normal(batch["xs"].shape)       # open gaps: every term of the sweep is exercised
+    us = batch["us"] + 1e-3 * rng.standard_normal(batch["us"].shape)
+    xs[:, 0] = batch["x0"]
+    eng = DdpEngine(model, N, len(seeds), opts=dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3, waves_per_simd=wps),
+                    consts=batch.get("consts"))
+    clean = _run(eng, batch, xs, us, poison=False)
+    dirty = _run(eng, batch, xs, us, poison=True)
+    for a, b in zip(clean, dirty):
+        assert np.all(np.isfinite(b)), "a NaN out of the poisoned LDS reached the result"
+        assert np.array_equal(a, b)
