@@ -285,7 +285,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
     constexpr int RS = (NSTG + kThreadsMW - 1) / kThreadsMW;
     constexpr int kLast = kWavesMW - 1;
     static_assert(NX <= kWave, "one lane per state in the v' and Vx phases");
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    const int lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);   // uniform: indices and branches on it are scalar
     const int* ki = reinterpret_cast<const int*>(s + L::KI);
     const QSplit<NX> qm{s + L::VXX, SV, s + L::QU, SQ, s + L::DUMP};   // Q as the model code addresses it (LdsMW)
     double g1_acc = 0.0, g2_acc = 0.0, dv_acc = 0.0, qu_acc = 0.0;   // per-wave partial sums, combined after the sweep
@@ -819,7 +819,7 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
     constexpr int UPW = (NU + kWavesMW - 1) / kWavesMW;            // feedback rows per wave
     constexpr int kStagers = kThreadsMW - kWave;
     constexpr int NSB = 2 * NX + NU + NP;
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    const int lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);   // uniform: indices and branches on it are scalar
     const LdsCol X{s + L::RO_X + lane}, U{s + L::RO_U + lane};
     double* kf = s + L::RO_G;                                      // staged gains of one knot: kff [NU]
     double* kb = s + L::RO_K;                                      //                           K [NU][SG]
@@ -1027,7 +1027,7 @@ template <class M>
 __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s, const int b, const int slot) {
     using L = LdsMW<M>;
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NREC = M::NREC;
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int N = A.N;
     const sddp_options& o = A.o;
     const double* x0 = A.x0 + size_t(b) * NX;
@@ -1229,7 +1229,7 @@ template <class M>
 __global__ __launch_bounds__(kThreadsMW) void backward_kernel_mw(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double s[];
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NREC = M::NREC;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     if (b >= A.B) return;
     const int N = A.N;
     const double* P = A.P + size_t(b) * (N + 1) * NP;
