@@ -106,6 +106,11 @@ INSTANCES = [
     ("srbd37", "Srbd37", "srbd37"), ("srbd37_b", "Srbd37B", "srbd37"), ("srbd37_s", "Srbd37S", "srbd37"), ("srbd37_bs", "Srbd37BS", "srbd37"),
     ("lip30", "Lip30", "lip30"), ("srbd61", "Srbd61", "srbd61"),
 ]
+# Per-build compiler options.  srbd61 (one workgroup per CU, 512 registers a lane, still 1.8 KB of scratch): LLVM's
+# -sink-insts-to-avoid-spills moves hoisted loop-invariant address arithmetic back into the loops instead of spilling it:
+# 25.8 -> 27.3 k solves/s (profiles/r04/experiments/README.md).  Measured and NOT applied elsewhere: srbd13 -1 % (scratch 524 -> 288 B
+# but slower), srbd37 +2.3 % in the two-per-SIMD build and -3 % in the other, which share a translation unit.
+INSTANCE_FLAGS = {"srbd61": ["-mllvm", "-sink-insts-to-avoid-spills"]}
 HEADERS = ["sddp_kernels.hpp", "sddp_kernels_mw.hpp", "sddp_models.hpp", "sddp_sort.hpp", "sddp_handle.hpp", "sddp_launch.hpp", "sddp_kernels_host.hpp"]
 
 
@@ -132,7 +137,7 @@ def build(force: bool = False, verbose: bool = False, only=None) -> str:
     inst = os.path.join(CSRC, "sddp_inst.hip")
     for fn, model, mname in INSTANCES:
         jobs.append((os.path.join(objdir, "inst_" + fn + ".o"), inst,
-                     ["-DSDDP_INST_MODEL=" + model, "-DSDDP_INST_FN=ops_" + fn, '-DSDDP_INST_NAME="' + mname + '"']))
+                     ["-DSDDP_INST_MODEL=" + model, "-DSDDP_INST_FN=ops_" + fn, '-DSDDP_INST_NAME="' + mname + '"', *INSTANCE_FLAGS.get(fn, [])]))
     todo = []
     for obj, src, defs in jobs:
         picked = only is not None and any(obj.endswith("inst_" + o + ".o") for o in only)
