@@ -48,6 +48,15 @@ constexpr bool mw_wfree() {
 #endif
 }
 
+// Whether a build of the kernel recomputes per knot what derives from the thread index (row / column decodes, LDS and HBM addresses)
+// instead of carrying it across the knot loops: the thread index passes through an opaque register copy at the top of every knot, so
+// LLVM's loop-invariant code motion has nothing to hoist.  Where registers are short the hoisted values are spilled, and a spill
+// reload is a `s_waitcnt vmcnt(0)` behind the knot's prefetch (loads return in order).  The half-register-file builds and the wide
+// model: scratch of solve_kernel_mw_w2<srbd37> 1 500 -> 1 324 B, + 3 % (srbd37, lip30), + 1.5 % (srbd61); the full-register-file
+// builds of srbd37 / lip30 lose 4.5 % with it (profiles/r04/experiments/README.md).
+template <class M>
+constexpr bool mw_sink(bool half_register_file) { return half_register_file || M::NX > 40; }
+
 #ifndef SDDP_MW_W2_WAVES
 #define SDDP_MW_W2_WAVES 2      // diagnostic: 3 = the half-register-file build capped at a third of the register file instead
 #endif
@@ -270,7 +279,7 @@ __device__ void mw_const_block(const DevConsts& c, int tid, double (&qconst)[Lds
 }
 
 // backward Riccati sweep on 4 waves; every thread gets the same return value and the same dV1 / G1 / G2 / qu_inf.
-template <class M>
+template <class M, bool SINK = false>
 __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __restrict__ P, const double* __restrict__ dft,
                                   const double* __restrict__ rec, double* __restrict__ gains, double mu, double theta,
                                   double* s, int tid, double& dV1, double& G1, double& G2, double& qu_inf,
@@ -285,7 +294,8 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
     constexpr int RS = (NSTG + kThreadsMW - 1) / kThreadsMW;
     constexpr int kLast = kWavesMW - 1;
     static_assert(NX <= kWave, "one lane per state in the v' and Vx phases");
-    const int lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);   // uniform: indices and branches on it are scalar
+    int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);   // uniform: indices and branches on it are scalar
     const int* ki = reinterpret_cast<const int*>(s + L::KI);
     const QSplit<NX> qm{s + L::VXX, SV, s + L::QU, SQ, s + L::DUMP};   // Q as the model code addresses it (LdsMW)
     double g1_acc = 0.0, g2_acc = 0.0, dv_acc = 0.0, qu_acc = 0.0;   // per-wave partial sums, combined after the sweep
@@ -347,6 +357,10 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
     };
     __syncthreads();
     for (int k = N - 1; k >= 0; --k) {
+        if constexpr (SINK) {   // (mw_sink: nothing derived from the thread index is carried across knots -- it would be spilled)
+            asm volatile("" : "+v"(tid));
+            lane = tid & (kWave - 1);
+        }
         // ---- stage this knot from the prefetch registers; start the next knot's loads; the previous knot's gains go out
 #pragma unroll
         for (int t = 0; t < RS; ++t) {
@@ -809,7 +823,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
 // Per knot: (A) wave 0 closes the previous knot, (B) every wave computes its rows of the feedback law, (C) wave 0 steps the
 // model while the other waves fetch the next knot's operands (gains, x_k, u_k, d_k, p_k: coalesced loads into LDS, read back
 // as broadcasts) and write the stored lane's x_k / u_k to HBM.
-template <class M, bool OPEN_LOOP>
+template <class M, bool OPEN_LOOP, bool SINK = false>
 __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
                              const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
                              const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
@@ -819,7 +833,8 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
     constexpr int UPW = (NU + kWavesMW - 1) / kWavesMW;            // feedback rows per wave
     constexpr int kStagers = kThreadsMW - kWave;
     constexpr int NSB = 2 * NX + NU + NP;
-    const int lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);   // uniform: indices and branches on it are scalar
+    int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);   // uniform: indices and branches on it are scalar
     const LdsCol X{s + L::RO_X + lane}, U{s + L::RO_U + lane};
     double* kf = s + L::RO_G;                                      // staged gains of one knot: kff [NU]
     double* kb = s + L::RO_K;                                      //                           K [NU][SG]
@@ -829,7 +844,7 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
     // registers allow (kEarlyFetch) the loads are issued before the feedback phase and land during it.
     constexpr int TS = (NSB + kStagers - 1) / kStagers, TG = (NG + kStagers - 1) / kStagers;
     constexpr bool kEarlyFetch = false;
-    const int se = tid - kWave;
+    int se = tid - kWave;
     double r_s[TS], r_g[TG];
     auto fetch_knot = [&](int k) {
         if (!OPEN_LOOP) {
@@ -876,6 +891,11 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
     double J = 0.0;
     const double oma = 1.0 - alpha;
     for (int k = 0; k < N; ++k) {
+        if constexpr (SINK) {
+            asm volatile("" : "+v"(tid));
+            lane = tid & (kWave - 1);
+            se = tid - kWave;
+        }
         SDDP_TICK(8)
         const double* sb = s + L::RO_S + (k & 1) * L::SB_N;
         // (x_k is in the X columns: x0, or written by the step of knot k - 1, which also closed that knot -- LdsColClose)
@@ -1023,7 +1043,7 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
 }
 
 // fused persistent solve, 4 waves per instance
-template <class M>
+template <class M, bool SINK>
 __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s, const int b, const int slot) {
     using L = LdsMW<M>;
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NREC = M::NREC;
@@ -1047,7 +1067,7 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
     mw_const_block<M>(A.c, tid, qconst);
     // ---- starting point (cost and defect norm computed by wave 0, shared through CTL)
     if (o.initial_rollout) {
-        J = rollout_mw<M, true>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, tid, s SDDP_T_PASS);
+        J = rollout_mw<M, true, SINK>(A.c, N, x0, P, xs, us, dft, gains, xn, un, 0.0, 0, tid, s SDDP_T_PASS);
         __syncthreads();
         for (int e = tid; e < (N + 1) * NX; e += kThreadsMW) xs[e] = xn[e];
         for (int e = tid; e < N * NX; e += kThreadsMW) dft[e] = 0.0;
@@ -1080,7 +1100,7 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
             bool ok = true, stop = false, accepted = false;
             do {   // at most twice: a failed sweep / line search with the second-order term is redone without it
                 while (true) {
-                    ok = backward_sweep_mw<M>(A.c, N, P, dft, rec, gains, mu, theta, s, tid, dV1, G1, G2, qu_inf, qconst SDDP_T_PASS);
+                    ok = backward_sweep_mw<M, SINK>(A.c, N, P, dft, rec, gains, mu, theta, s, tid, dV1, G1, G2, qu_inf, qconst SDDP_T_PASS);
                     if (ok) break;
                     if (theta != 0.0) { theta = 0.0; continue; }
                     mu = fmax(mu, 0.0) * 10.0 + o.mu_min;
@@ -1102,7 +1122,7 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
                     for (int j = 0; j < lane; ++j) a *= o.line_search_decrease_factor;
                     const bool valid = a >= o.alpha_converge_threshold;
                     SDDP_TICK(9)
-                    const double Jl = rollout_mw<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, guess, tid, s SDDP_T_PASS);
+                    const double Jl = rollout_mw<M, false, SINK>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, guess, tid, s SDDP_T_PASS);
                     SDDP_TICK(8)
                     tiles_dirty = true;
                     ++rollouts;
@@ -1121,7 +1141,7 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
                         a_win = __shfl(a, win, kWave);
                         J_win = s[L::CTL + 13];
                         if (win != guess) {   // the accepted lane's trajectory was not the one stored: roll it again
-                            rollout_mw<M, false>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, tid, s SDDP_T_PASS);
+                            rollout_mw<M, false, SINK>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, tid, s SDDP_T_PASS);
                             ++rollouts;
                         }
                         guess = win;
@@ -1188,7 +1208,7 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
 }
 
 // work queue over the resident workgroups (see solve_queue in sddp_kernels.hpp); the queue position travels through LDS
-template <class M>
+template <class M, bool SINK>
 __device__ __forceinline__ void solve_queue_mw(const SolveArgs& A, double* s) {
     // the queue position lives in a control word of the dynamic LDS block (CTL + 15), so that the occupancy query and the
     // dynamic-LDS attribute cover every byte of LDS the kernel uses
@@ -1202,7 +1222,7 @@ __device__ __forceinline__ void solve_queue_mw(const SolveArgs& A, double* s) {
     __syncthreads();                                   // every thread has read it before the solve re-zeroes the LDS block
     while (i < A.count) {
         const int b = (queued && A.order) ? A.order[i] : A.first + i;
-        solve_instance_mw<M>(A, s, b, slot);           // ends with a barrier: q_pos may be rewritten
+        solve_instance_mw<M, SINK>(A, s, b, slot);           // ends with a barrier: q_pos may be rewritten
         if (!queued) break;
         if (threadIdx.x == 0) *q_pos = atomicAdd(A.qhead, 1);
         __syncthreads();
@@ -1214,7 +1234,7 @@ __device__ __forceinline__ void solve_queue_mw(const SolveArgs& A, double* s) {
 template <class M>
 __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double s[];
-    solve_queue_mw<M>(A, s);
+    solve_queue_mw<M, mw_sink<M>(false)>(A, s);
 }
 
 // the same body capped at half the register file: two workgroups per CU where the tiles of two instances fit its LDS;
@@ -1222,7 +1242,7 @@ __global__ __launch_bounds__(kThreadsMW) void solve_kernel_mw(SolveArgs A) {
 template <class M>
 __global__ __launch_bounds__(kThreadsMW) __attribute__((amdgpu_waves_per_eu(SDDP_MW_W2_WAVES))) void solve_kernel_mw_w2(SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double s[];
-    solve_queue_mw<M>(A, s);
+    solve_queue_mw<M, mw_sink<M>(true)>(A, s);
 }
 
 template <class M>
@@ -1249,7 +1269,7 @@ __global__ __launch_bounds__(kThreadsMW) void backward_kernel_mw(SolveArgs A) {
     double dV1, G1, G2, qu_inf;
     double qconst[LdsMW<M>::TQ][3][3];
     mw_const_block<M>(A.c, tid, qconst);
-    const bool ok = backward_sweep_mw<M>(A.c, N, P, dft, rec, gains, A.mu, A.alpha, s, tid, dV1, G1, G2, qu_inf, qconst SDDP_T_PASS);
+    const bool ok = backward_sweep_mw<M, mw_sink<M>(false)>(A.c, N, P, dft, rec, gains, A.mu, A.alpha, s, tid, dV1, G1, G2, qu_inf, qconst SDDP_T_PASS);
     if (tid == 0) {
         double* sc = A.scal + size_t(b) * kScal;
         sc[0] = dV1; sc[1] = -0.5 * dV1; sc[2] = G1; sc[3] = G2; sc[4] = ok ? 1.0 : 0.0; sc[5] = A.mu; sc[6] = qu_inf; sc[7] = J;
@@ -1264,7 +1284,7 @@ __global__ __launch_bounds__(kThreadsMW) void forward_kernel_mw(SolveArgs A) {
     if (b >= A.B) return;
     const int N = A.N;
     SDDP_T_DECL
-    const double J = rollout_mw<M, false>(A.c, N, A.x0 + size_t(b) * NX, A.P + size_t(b) * (N + 1) * NP,
+    const double J = rollout_mw<M, false, mw_sink<M>(false)>(A.c, N, A.x0 + size_t(b) * NX, A.P + size_t(b) * (N + 1) * NP,
                                           A.xs + size_t(b) * (N + 1) * NX, A.us + size_t(b) * N * NU,
                                           A.dft + size_t(b) * N * NX, A.gains + size_t(b) * N * (NU * (NX + 1)),
                                           A.xn + size_t(b) * (N + 1) * NX, A.un + size_t(b) * N * NU, A.alpha, 0, tid, s SDDP_T_PASS);
