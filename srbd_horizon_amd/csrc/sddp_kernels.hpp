@@ -398,8 +398,8 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         if (t_on) s[t_dst] = r_rec[RREC - 1];
         if (!MERGE_P && lane < NP) s[L::PK + lane] = r_p;
         if (has_gap && lane < NX) s[L::DK + lane] = r_d;
-        if (k > 0) fetch(k - 1);
         if (k < N - 1) store_gains(k + 1);
+        if (k > 0) fetch(k - 1);
         wave_sync();
         SDDP_TICK(1)
         const double state = k >= 1 ? 1.0 : 0.0;
