@@ -684,17 +684,19 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
     }
     double r_x = 0, r_u = 0, r_p = 0, r_d = 0, r_m = 0, r_g[RG];
     auto fetch = [&](int k) {
+        // the gain rows first: their registers are zero-filled for the lanes past the row's end, and that write waits for whatever
+        // the compiler still counts as pending on those registers -- in front of the knot's first load it waits for nothing
+        if (!OPEN_LOOP) {
+            const double* gk = gains + size_t(k) * NG;
+#pragma unroll
+            for (int t = 0; t < RG; ++t) r_g[t] = (lane + t * kWave < NG) ? gk[lane + t * kWave] : 0.0;
+        }
         if (MERGED) {
             if (m_on) r_m = m_src[size_t(k) * m_stride];
         } else {
             if (lane < NU) r_u = us[k * NU + lane];
             if (lane < NP) r_p = P[k * NP + lane];
             if (!OPEN_LOOP && lane < NX) { r_x = xs[k * NX + lane]; r_d = dft[k * NX + lane]; }
-        }
-        if (!OPEN_LOOP) {
-            const double* gk = gains + size_t(k) * NG;
-#pragma unroll
-            for (int t = 0; t < RG; ++t) r_g[t] = (lane + t * kWave < NG) ? gk[lane + t * kWave] : 0.0;
         }
     };
     fetch(0);
