@@ -83,6 +83,11 @@ struct SolveArgs {
 // later ds_read of any lane sees an earlier ds_write of any lane without waiting; what must not happen is the COMPILER moving
 // accesses across the hand-off.  A wavefront-scope fence does exactly that and costs no instruction, where __syncthreads()
 // costs an s_waitcnt lgkmcnt(0) that also drains loads still in flight.  (The 4-wave kernels use real barriers.)
+// s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt 0, expcnt / lgkmcnt at their maxima): every load and store of this wave has completed.
+// In front of a knot loop: whatever the code before the loop left in flight is otherwise "pending" on the loop's entry edge in the
+// compiler's wait-count bookkeeping, and the waits it inserts for that stay inside the loop body, behind the knot's prefetch.
+__device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -390,6 +395,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         for (int t = 0; t < RGW; ++t)
             if (lane + t * kWave < NGW) gk[lane + t * kWave] = v[t];
     };
+    drain_vmem();
     fetch(N - 1);
     for (int k = N - 1; k >= 0; --k) {
         // ---- stage this knot from the prefetch registers; start the next knot's loads; then the previous knot's gains go out
@@ -699,6 +705,7 @@ __device__ double rollout(const DevConsts& c, int N, const double* __restrict__ 
             if (!OPEN_LOOP && lane < NX) { r_x = xs[k * NX + lane]; r_d = dft[k * NX + lane]; }
         }
     };
+    drain_vmem();
     fetch(0);
     double J = 0.0;
     const double oma = 1.0 - alpha;
