@@ -998,18 +998,22 @@ __device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict
                     pin_regs(xkv);
 #pragma unroll
                     for (int j = 0; j < CH; ++j) dx[j] = c0 + j < NX ? xv[j] - xkv[j] : 0.0;     // columns past nx: multiplied by 0
-                    double gb[2][CH];
+                    // gain rows RING - 1 rows ahead of the row being used: one wave per SIMD has nothing else to cover an LDS round trip
+                    // (one row ahead = 10 FMAs = 40 cycles against > 100)
+                    constexpr int RING = 4;
+                    double gb[RING][CH];
                     auto load_unit = [&](int r, double (&dst)[CH]) {
                         const int i = wave * UPW + r < NU ? wave * UPW + r : NU - 1;
                         load_run<CH>(kb + i * SG + c0, dst);                                      // c0, SG even: ds_read_b128
                     };
-                    load_unit(0, gb[0]);
+#pragma unroll
+                    for (int r = 0; r < RING - 1 && r < UPW; ++r) load_unit(r, gb[r]);
 #pragma unroll
                     for (int r = 0; r < UPW; ++r) {
-                        if (r + 1 < UPW) load_unit(r + 1, gb[(r + 1) & 1]);
-                        pin_regs(gb[r & 1]);
+                        if (r + RING - 1 < UPW) load_unit(r + RING - 1, gb[(r + RING - 1) % RING]);
+                        pin_regs(gb[r % RING]);
 #pragma unroll
-                        for (int j = 0; j < CH; ++j) acc[r] = fma(gb[r & 1][j], dx[j], acc[r]);
+                        for (int j = 0; j < CH; ++j) acc[r] = fma(gb[r % RING][j], dx[j], acc[r]);
                     }
                 }
 #pragma unroll
