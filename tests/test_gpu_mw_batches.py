@@ -1,6 +1,7 @@
 """Whole bench batches of the 4-wavefront kernel against the plain-C oracle: the `srbd37_n20_batch` (2048 cold instances of the
-reference's own problem, two workgroups per CU, through the work queue) and `srbd61_n20_batch` (1024 instances of its code-default
-contact configuration) extras of bench.py -- every instance: same iteration count, status and convergence flag, the same trajectory
+reference's own problem, two workgroups per CU, through the work queue), `srbd37_n60_batch` (BASELINE configs[4]'s shape, 1024
+instances), `lip30_n20_batch` (4096) and `srbd61_n20_batch` (1024 instances of the code-default contact configuration) extras of
+bench.py -- every instance: same iteration count, status and convergence flag, the same trajectory
 at the north_star tolerance.  The counts go to the warnings summary (PARITY-COUNT) like those of the srbd13 batches."""
 import numpy as np
 import pytest
@@ -17,7 +18,7 @@ OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsr
 MW_BATCH_ALLOWED = 1                                                      # the shipped build shows 0 of 2048 and 0 of 1024 (PARITY-COUNT)
 
 
-@pytest.mark.parametrize("model,N,B,wps", [("srbd37", 20, 2048, 2), ("srbd61", 20, 1024, 1)])
+@pytest.mark.parametrize("model,N,B,wps", [("srbd37", 20, 2048, 2), ("srbd37", 60, 1024, 2), ("lip30", 20, 4096, 2), ("srbd61", 20, 1024, 1)])
 def test_whole_batch_matches_the_c_oracle(model, N, B, wps, record_property):
     batch = workload.make_batch(model, N, np.arange(B))
     eng = DdpEngine(model, N, B, opts=dict(OPTS, waves_per_simd=wps, queue_order=2), consts=batch["consts"])
@@ -26,7 +27,7 @@ def test_whole_batch_matches_the_c_oracle(model, N, B, wps, record_property):
     st = eng.stats.copy()
     slots, grid, queued = eng.queue_info()
     assert queued == B and grid == slots < B                                # the launch was a queue on the resident workgroups
-    xo, uo, so = cport.solve_batch(omodels.make_model(model).cst if model != "srbd37" else omodels.RobotConsts(**batch["consts"]),
+    xo, uo, so = cport.solve_batch(omodels.make_model(model).cst if model == "srbd61" else omodels.RobotConsts(**batch["consts"]),
                                    oddp.DdpOptions(**OPTS), batch["x0"], batch["params"], batch["xs"], batch["us"], threads=8, model=model)
     it_o = so[:, 1].astype(int)
     same = st["iters"] == it_o
