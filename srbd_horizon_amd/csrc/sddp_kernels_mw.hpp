@@ -15,7 +15,7 @@
 //   * Every wave keeps an identical copy of the scalar solver state (cost, merit weight, regularisation, counters); values
 //     produced by one wave only reach the others through the control words CTL[..] behind a workgroup barrier.
 //
-//   * LDS per instance: 50.9 KB (srbd37; two workgroups share a CU: solve_kernel_mw_w2), 32.0 KB (lip30), 145.3 KB (srbd61, one
+//   * LDS per instance: 52.0 KB (srbd37; two workgroups share a CU: solve_kernel_mw_w2), 32.0 KB (lip30), 149.9 KB (srbd61, one
 //     per CU); Q has no tile of its own -- see LdsMW.  tests/test_lds_budget.py pins these.
 //
 // These models need > 40 KB of LDS per instance (<= 2 workgroups per CU at 256 registers), so the 4 waves do not fight the
@@ -34,7 +34,7 @@ __host__ __device__ constexpr int round_up(int n, int m) { return (n + m - 1) / 
 __host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 
 // Whether the sweep of model M runs WITHOUT the dense (Vxx F)^T tile ("W-free"): the SRBD models, whose
-// [fx fu] has dense rows (ND > 0).  srbd61's tiles would not fit a CU's 160 KB with the tile; srbd37 drops from 63.8 to 50.9 KB and
+// [fx fu] has dense rows (ND > 0).  srbd61's tiles would not fit a CU's 160 KB with the tile; srbd37 drops from 63.8 to 50.9 KB (52.0 with the Gauss-Jordan's multiplier block) and
 // gains 14 % at two workgroups per CU (the W phase becomes a compact 111 x 7 product).  lip30 (no dense rows: the tile IS the
 // product) keeps it: measured neutral to - 1 % without.  -DSDDP_WFREE_ALL / -DSDDP_WFREE_NONE: diagnostic builds.
 template <class M>
@@ -128,9 +128,12 @@ struct LdsMW {
     // the gain tile and the Gauss-Jordan hand-off rows live where WT (W-free: GC | WC) is dead: after the Q phase, until the next knot
     static constexpr int KT = WT;                       // KT [NX][SK]: KT[c][i] = K[i][c]
     static constexpr int GT = KT + ((NX * SK + 1) & ~1);   // hand-off rows, double buffered [2][RPW][GTS]
+    static constexpr int RPWE = (RPW + 1) & ~1;
+    static constexpr int MU = GT + 2 * RPW * GTS;          // each wave's multipliers for the block being eliminated [4][RPW][RPWE] (row r: its RPW rows)
+    static constexpr int MU_END = MU + kWavesMW * RPW * RPWE;
     static constexpr int GC = WT;                                                              // W-free only
-    static constexpr int WC = WFREE ? GC + RZ * SGC : imax(WT + RZ * SV, GT + 2 * RPW * GTS);  // (small models: the tile is sized by what it hosts)
-    static constexpr int QU = WFREE ? imax(WC + RZ * SC, GT + 2 * RPW * GTS) : WC + RZ * SC;   // [NU][SQ]: row i = row NX + i of Q (columns: state | input)
+    static constexpr int WC = WFREE ? GC + RZ * SGC : imax(WT + RZ * SV, MU_END);              // (small models: the tile is sized by what it hosts)
+    static constexpr int QU = WFREE ? imax(WC + RZ * SC, MU_END) : WC + RZ * SC;               // [NU][SQ]: row i = row NX + i of Q (columns: state | input)
     static constexpr int SWEEP_END = QU + NU * SQ;
     // forward pass: per-lane vector columns X | U and the staged gains of one knot
     static constexpr int RO_X = WORK, RO_U = RO_X + NX * kWave, RO_G = RO_U + NU * kWave;
@@ -142,7 +145,7 @@ struct LdsMW {
     static constexpr int RO_END = RO_S + 2 * SB_N;
     static constexpr int TOTAL = imax(SWEEP_END, RO_END);
     static constexpr size_t BYTES = size_t(TOTAL) * sizeof(double);
-    static_assert((FC | VX | VP | QV | REC | PK | DK | KT | KF | GT | GC | DS | DG | LS | LG | CTL | BET | IDC | KI | WORK | WT | WC | QU | RO_G) % 2 == 0, "16-byte aligned sections");
+    static_assert((FC | VX | VP | QV | REC | PK | DK | KT | KF | GT | MU | GC | DS | DG | LS | LG | CTL | BET | IDC | KI | WORK | WT | WC | QU | RO_G) % 2 == 0, "16-byte aligned sections");
     static_assert(BYTES <= size_t(160) * 1024, "the tiles of one instance must fit a CU's LDS");
     static_assert(NU < kWave, "the pivot columns and the Qu column sit in the first column of every lane");
 };
@@ -677,54 +680,63 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
                         for (int cc = 0; cc < CPL; ++cc) gt[r * GTS + lane + kWave * cc] = a[r][cc];
                     if (lane == 0) s[L::CTL + 14 + (blk & 1)] = ok ? 1.0 : 0.0;
                 }
+                // The multipliers of this block -- a[rr] in the lanes of the block's pivot columns -- go to LDS while the owner reduces
+                // its rows; the apply step below reads them back as broadcasts (one ds_read_b128 per two multipliers instead of two
+                // v_readlane per multiplier; the same values, so the same results).
+                double* mul = s + L::MU + wave * RPW * L::RPWE;
+                if (wave != blk) {
+                    const int r = lane - blk * RPW;
+                    if (r >= 0 && r < RPW) {
+#pragma unroll
+                        for (int rr = 0; rr < RPW; ++rr) mul[r * L::RPWE + rr] = a[rr][0];
+                    }
+                }
                 SDDP_TICK(17)
                 __syncthreads();
                 SDDP_TICK(18)
                 if (s[L::CTL + 14 + (blk & 1)] == 0.0) return false;
                 if (wave != blk) {
                     if constexpr (RPW * RPW <= 36) {
-                        double pv[RPW][RPW], tv[RPW][CPL];
+                        double pv[RPW][L::RPWE], tv[RPW][CPL];
 #pragma unroll
                         for (int r = 0; r < RPW; ++r)
 #pragma unroll
-                            for (int cc = 0; cc < CPL; ++cc) tv[r][cc] = gt[r * GTS + lane + kWave * cc];       // in flight behind the broadcasts below
+                            for (int cc = 0; cc < CPL; ++cc) tv[r][cc] = gt[r * GTS + lane + kWave * cc];
 #pragma unroll
-                        for (int rr = 0; rr < RPW; ++rr)
+                        for (int r = 0; r < RPW; ++r) load_run<L::RPWE>(mul + r * L::RPWE, pv[r]);             // pv[r][rr]: multiplier of row rr against published row r
 #pragma unroll
-                            for (int r = 0; r < RPW; ++r) pv[rr][r] = readlane_d(a[rr][0], min(blk * RPW + r, NU - 1));
-#pragma unroll
-                        for (int r = 0; r < RPW; ++r) pin_regs(tv[r]);
+                        for (int r = 0; r < RPW; ++r) { pin_regs(tv[r]); pin_regs(pv[r]); }
 #pragma unroll
                         for (int r = 0; r < RPW; ++r) {
                             if (blk * RPW + r < NU) {
 #pragma unroll
                                 for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-                                    for (int cc = 0; cc < CPL; ++cc) a[rr][cc] = fma(-pv[rr][r], tv[r][cc], a[rr][cc]);
+                                    for (int cc = 0; cc < CPL; ++cc) a[rr][cc] = fma(-pv[r][rr], tv[r][cc], a[rr][cc]);
                             }
                         }
                     } else {
                         // many rows per wave: the multipliers of one published row at a time (RPW x RPW of them do not fit the
                         // registers).  Row r of the reduced block is the unit vector in the block's own columns but for rounding,
                         // so the multiplier a[rr] at lane p_r is still the original entry when row r is reached.
-                        double tv[2][CPL];
+                        double tv[2][CPL], pv[2][L::RPWE];
 #pragma unroll
                         for (int cc = 0; cc < CPL; ++cc) tv[0][cc] = gt[lane + kWave * cc];
+                        load_run<L::RPWE>(mul, pv[0]);
 #pragma unroll
                         for (int r = 0; r < RPW; ++r) {
                             if (r + 1 < RPW) {
 #pragma unroll
                                 for (int cc = 0; cc < CPL; ++cc) tv[(r + 1) & 1][cc] = gt[(r + 1) * GTS + lane + kWave * cc];
+                                load_run<L::RPWE>(mul + (r + 1) * L::RPWE, pv[(r + 1) & 1]);
                             }
-                            double pv[RPW];
-#pragma unroll
-                            for (int rr = 0; rr < RPW; ++rr) pv[rr] = readlane_d(a[rr][0], min(blk * RPW + r, NU - 1));
                             pin_regs(tv[r & 1]);
+                            pin_regs(pv[r & 1]);
                             if (blk * RPW + r < NU) {
 #pragma unroll
                                 for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-                                    for (int cc = 0; cc < CPL; ++cc) a[rr][cc] = fma(-pv[rr], tv[r & 1][cc], a[rr][cc]);
+                                    for (int cc = 0; cc < CPL; ++cc) a[rr][cc] = fma(-pv[r & 1][rr], tv[r & 1][cc], a[rr][cc]);
                             }
                         }
                     }
