@@ -283,7 +283,7 @@ __device__ void mw_const_block(const DevConsts& c, int tid, double (&qconst)[Lds
 
 // backward Riccati sweep on 4 waves; every thread gets the same return value and the same dV1 / G1 / G2 / qu_inf.
 template <class M, bool SINK = false>
-__device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __restrict__ P, const double* __restrict__ dft,
+__device__ __forceinline__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __restrict__ P, const double* __restrict__ dft,
                                   const double* __restrict__ rec, double* __restrict__ gains, double mu, double theta,
                                   double* s, int tid, double& dV1, double& G1, double& G2, double& qu_inf,
                                   const double (&qconst)[LdsMW<M>::TQ][3][3] SDDP_T_ARG) {
@@ -836,7 +836,7 @@ __device__ bool backward_sweep_mw(const DevConsts& c, int N, const double* __res
 // model while the other waves fetch the next knot's operands (gains, x_k, u_k, d_k, p_k: coalesced loads into LDS, read back
 // as broadcasts) and write the stored lane's x_k / u_k to HBM.
 template <class M, bool OPEN_LOOP, bool SINK = false>
-__device__ double rollout_mw(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
+__device__ __forceinline__ double rollout_mw(const DevConsts& c, int N, const double* __restrict__ x0, const double* __restrict__ P,
                              const double* __restrict__ xs, const double* __restrict__ us, const double* __restrict__ dft,
                              const double* __restrict__ gains, double* __restrict__ xn, double* __restrict__ un,
                              double alpha, int store_lane, int tid, double* s SDDP_T_ARG) {
@@ -1133,15 +1133,23 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
                 accepted = false;
                 bool tiles_dirty = false;
                 double a_base = o.alpha_0;
+                // Wide models: ONE call site of the pass (a pass that only has to store another lane's trajectory is a second trip of
+                // this loop).  With two, the compiler keeps the pass of srbd61 out of line: a real call, generic pointers (flat loads),
+                // the constants by reference through scratch -- 28.9 -> 31.8 k solves/s.  The narrow models keep their two inlined
+                // copies (one call site costs them 2 %).
+                constexpr bool kOneCallSite = M::NX > 40;
+                int reroll = -1;
                 while (a_base >= o.alpha_converge_threshold) {
                     double a = a_base;
                     for (int j = 0; j < lane; ++j) a *= o.line_search_decrease_factor;
                     const bool valid = a >= o.alpha_converge_threshold;
                     SDDP_TICK(9)
-                    const double Jl = rollout_mw<M, false, SINK>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, guess, tid, s SDDP_T_PASS);
+                    const double Jl = rollout_mw<M, false, SINK>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a,
+                                                                 kOneCallSite && reroll >= 0 ? reroll : guess, tid, s SDDP_T_PASS);
                     SDDP_TICK(8)
                     tiles_dirty = true;
                     ++rollouts;
+                    if (kOneCallSite && reroll >= 0) { guess = reroll; accepted = true; break; }
                     if (wave == 0) {
                         const double pred = a * A1 + a * a * B2 - a * rho * gap;
                         const double dphi = (Jl + rho * (1.0 - a) * gap) - (J + rho * gap);
@@ -1157,8 +1165,11 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
                         a_win = __shfl(a, win, kWave);
                         J_win = s[L::CTL + 13];
                         if (win != guess) {   // the accepted lane's trajectory was not the one stored: roll it again
-                            rollout_mw<M, false, SINK>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, tid, s SDDP_T_PASS);
-                            ++rollouts;
+                            if constexpr (kOneCallSite) { reroll = win; continue; }
+                            else {
+                                rollout_mw<M, false, SINK>(A.c, N, x0, P, xs, us, dft, gains, xn, un, a, win, tid, s SDDP_T_PASS);
+                                ++rollouts;
+                            }
                         }
                         guess = win;
                         accepted = true;

@@ -984,6 +984,9 @@ struct SrbdModel {
         double otg = p_otg(p), o0 = p_oref(p, 0), o1 = p_oref(p, 1), o2 = p_oref(p, 2), o3 = p_oref(p, 3);
         double sw = p_sw(p, ci);
         asm volatile("" : "+v"(otg), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(sw));
+        // (state / stage through the same pin: `stage * 2 * c.w_sw` is otherwise hoisted out of the callers' loops as a VALU result, spilled
+        // where registers are short, and every call then waits for a scratch reload -- two multiplications cost less)
+        asm volatile("" : "+v"(state), "+v"(stage));
         const double n2 = o0 * o0 + o1 * o1 + o2 * o2 + o3 * o3;
         const double v1 = state * 2 * otg * otg * n2;
         const double v2 = stage * 2 * c.w_sw * (1.0 - sw) * (1.0 - sw);
