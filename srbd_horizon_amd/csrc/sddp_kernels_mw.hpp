@@ -566,9 +566,9 @@ __device__ __forceinline__ bool backward_sweep_mw(const DevConsts& c, int N, con
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) acc[i][j] = qacc[tq][i][j];
-                if constexpr (ND > 0) dot_block<3, 3, L::DG8, (TQ > 1 ? 1 : 2)>(s + L::GC + a0 * L::SGC, L::SGC, s + L::FC + b0 * SC, SC, acc);
+                if constexpr (ND > 0) dot_block<3, 3, L::DG8>(s + L::GC + a0 * L::SGC, L::SGC, s + L::FC + b0 * SC, SC, acc);
             }
-            dot_block<3, 3, SC, (TQ > 1 ? 1 : 2)>(s + L::FC + a0 * SC, SC, s + L::WC + b0 * SC, SC, acc);
+            dot_block<3, 3, SC>(s + L::FC + a0 * SC, SC, s + L::WC + b0 * SC, SC, acc);
             if (NEV < NE && TQ == 1) {      // (several blocks per thread: the constant rows are a sparse pass after the barrier)
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
