@@ -775,6 +775,57 @@ __device__ __forceinline__ bool backward_sweep_mw(const DevConsts& c, int N, con
             for (int i = 0; i < NU; ++i) acc += qr[i] * kv[i];
             s[L::VX + lane] = acc;
         }
+        if constexpr (TV > 1) {
+            // several blocks per thread (srbd61, one wave per SIMD): their products run INTERLEAVED -- TV independent chains and TV times
+            // the LDS reads in flight per input row; one block after the other leaves every round trip exposed.  Same sums, same order.
+            int a0[TV], c0[TV], a1[TV], c1[TV];
+            bool on[TV];
+            double v[TV][4];
+#pragma unroll
+            for (int tv = 0; tv < TV; ++tv) {
+                on[tv] = tid + tv * kThreadsMW < L::NTRIV;
+                const int code = on[tv] ? code_v[tv] : 0;
+                a0[tv] = 2 * (code >> 8); c0[tv] = 2 * (code & 255);
+                a1[tv] = a0[tv] + 1 < NX ? a0[tv] + 1 : a0[tv]; c1[tv] = c0[tv] + 1 < NX ? c0[tv] + 1 : c0[tv];
+                v[tv][0] = v[tv][1] = v[tv][2] = v[tv][3] = 0.0;
+            }
+#pragma unroll 4
+            for (int i = 0; i < NU; ++i) {
+                double2_t q2[TV];
+                double kc[TV], kd[TV];
+#pragma unroll
+                for (int tv = 0; tv < TV; ++tv) {
+                    q2[tv] = lds2(s + L::QU + i * SQ + a0[tv]);
+                    kc[tv] = s[L::KT + c0[tv] * SK + i];
+                    kd[tv] = s[L::KT + c1[tv] * SK + i];
+                }
+#pragma unroll
+                for (int tv = 0; tv < TV; ++tv) {
+                    v[tv][0] = fma(q2[tv].x, kc[tv], v[tv][0]);
+                    v[tv][1] = fma(q2[tv].x, kd[tv], v[tv][1]);
+                    v[tv][2] = fma(q2[tv].y, kc[tv], v[tv][2]);
+                    v[tv][3] = fma(q2[tv].y, kd[tv], v[tv][3]);
+                }
+            }
+#pragma unroll
+            for (int tv = 0; tv < TV; ++tv) {
+                if (!on[tv]) continue;
+                double v00 = v[tv][0] + s[L::VXX + a0[tv] * SV + c0[tv]], v01 = v[tv][1] + s[L::VXX + a0[tv] * SV + c1[tv]];
+                double v10 = v[tv][2] + s[L::VXX + a1[tv] * SV + c0[tv]], v11 = v[tv][3] + s[L::VXX + a1[tv] * SV + c1[tv]];
+                if (a0[tv] == c0[tv]) { const double off = 0.5 * (v01 + v10); v01 = v10 = off; }
+                const bool ha = a0[tv] + 1 < NX, hc = c0[tv] + 1 < NX;
+                s[L::VXX + a0[tv] * SV + c0[tv]] = v00;
+                if (hc) s[L::VXX + a0[tv] * SV + c0[tv] + 1] = v01;
+                if (ha) s[L::VXX + (a0[tv] + 1) * SV + c0[tv]] = v10;
+                if (ha && hc) s[L::VXX + (a0[tv] + 1) * SV + c0[tv] + 1] = v11;
+                if (a0[tv] != c0[tv]) {
+                    s[L::VXX + c0[tv] * SV + a0[tv]] = v00;
+                    if (hc) s[L::VXX + (c0[tv] + 1) * SV + a0[tv]] = v01;
+                    if (ha) s[L::VXX + c0[tv] * SV + a0[tv] + 1] = v10;
+                    if (ha && hc) s[L::VXX + (c0[tv] + 1) * SV + a0[tv] + 1] = v11;
+                }
+            }
+        } else {
 #pragma unroll
         for (int tv = 0; tv < TV; ++tv) {
         if (tid + tv * kThreadsMW < L::NTRIV) {
@@ -808,6 +859,7 @@ __device__ __forceinline__ bool backward_sweep_mw(const DevConsts& c, int N, con
                 if (ha) s[L::VXX + c0 * SV + a0 + 1] = v10;
                 if (ha && hc) s[L::VXX + (c0 + 1) * SV + a0 + 1] = v11;
             }
+        }
         }
         }
         __syncthreads();
