@@ -16,6 +16,8 @@
 #include "sddp_kernels_host.hpp"
 #include "sddp_sort.hpp"
 
+static bool poison_every_launch();   // SDDP_POISON_LDS=1: test runs only (defined beside sddp_debug_poison_lds)
+
 using namespace sddp;
 
 // the model builds of the library (sddp_inst.hip, one translation unit each; srbd_horizon_amd/_lib.py INSTANCES)
@@ -418,6 +420,7 @@ int sddp_solve_range_device(sddp_handle* h, const double* d_params, int first, i
     if (!d_params) return fail(h, SDDP_ERR_ARG, "params is NULL");
     if (first < 0 || count < 1 || first > h->B - count) return fail(h, SDDP_ERR_ARG, "instance range outside the batch");
     SolveArgs a = make_args(h, d_params);
+    if (poison_every_launch()) sddp_debug_poison_lds(h);
     rc = h->ops->launch_solve(h, a, first, count);
     return rc;
 }
@@ -453,6 +456,13 @@ int sddp_kernel_resources(sddp_handle* h, int* vgprs, int* scratch_bytes_per_lan
     if (lds_bytes) *lds_bytes = h->last_lds + int(at.sharedSizeBytes);
     if (workgroups_per_cu) *workgroups_per_cu = h->last_per_cu;
     return SDDP_OK;
+}
+
+// SDDP_POISON_LDS=1 (test runs only): every solve / sweep / pass launch of the process is preceded by sddp_debug_poison_lds, so the
+// whole GPU suite can be run on NaN-filled LDS (tests/test_gpu_lds_poison.py covers the kernels; this covers every path to them).
+static bool poison_every_launch() {
+    static const bool on = [] { const char* e = getenv("SDDP_POISON_LDS"); return e && e[0] == '1'; }();
+    return on;
 }
 
 int sddp_debug_poison_lds(sddp_handle* h) {
@@ -765,6 +775,7 @@ int sddp_backward(sddp_handle* h, const double* params, double mu, double* gains
     HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     SolveArgs a = make_args(h, h->P);
     a.mu = mu;
+    if (poison_every_launch()) sddp_debug_poison_lds(h);
     rc = h->ops->launch_backward(h, a);
     if (rc != SDDP_OK) return rc;
     h->gains_by_instance = true;
@@ -789,6 +800,7 @@ int sddp_forward(sddp_handle* h, const double* params, double alpha, double* x_o
     HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     SolveArgs a = make_args(h, h->P);
     a.alpha = alpha;
+    if (poison_every_launch()) sddp_debug_poison_lds(h);
     rc = h->ops->launch_forward(h, a);
     if (rc != SDDP_OK) return rc;
     if (x_out) HIP_TRY(h, hipMemcpyAsync(x_out, h->xn, h->n_x() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
