@@ -202,7 +202,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from srbd_horizon_amd import workload
+    from srbd_horizon_amd import _lib, workload
     from srbd_horizon_amd.engine import DdpEngine
     from srbd_horizon_amd.fleet import FleetQueue
 
@@ -268,8 +268,8 @@ def main():
     def launch(fl, count):
         n = fl.flush()                                         # ONE launch over the pending batches (+ async all-gather)
         if count and n:
-            acc[0] += fl.si[:n, 10].sum()                      # sddp_stats.iters / .rollouts of the launch, summed on the stream
-            acc[1] += fl.si[:n, 13].sum()
+            acc[0] += fl.si[:n, _lib.STATS_I32_ITERS].sum()                      # sddp_stats.iters / .rollouts of the launch, summed on the stream
+            acc[1] += fl.si[:n, _lib.STATS_I32_ROLLOUTS].sum()
 
     def run_steps(fl, d, n_steps, count=False):
         for i in range(n_steps):
@@ -293,7 +293,7 @@ def main():
     acc.zero_()
     eng.synchronize()
     eng.kernel_time_stats(reset=True)
-    acc += fleet.si[:1, 10].sum()                              # (first use of these device ops is never inside the timed region)
+    acc += fleet.si[:1, _lib.STATS_I32_ITERS].sum()                              # (first use of these device ops is never inside the timed region)
     acc.zero_()
     barrier()
     # RUNS timed regions, each EXACTLY `steps` steps over seed blocks of its own, each bracketed by barrier + synchronize and
@@ -323,7 +323,6 @@ def main():
     tot_iters, tot_roll = med["iters"], med["rollouts"]
     timed_blocks = run_blocks[order_el[RUNS // 2]]
     d_t = d_runs[order_el[RUNS // 2]]
-    g0 = 0
     slots, last_grid, last_queued = eng.queue_info()
 
     n_last = (steps - Q * ((steps - 1) // Q)) * B              # instances of the last launch: what the handle still holds

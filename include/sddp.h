@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDDP_ABI_VERSION 8
+#define SDDP_ABI_VERSION 9
 
 /* model ids */
 #define SDDP_MODEL_SRBD13 0 /* nx=13 nu=6  np=19 : BASELINE.json metric model (contacts are per-knot parameters) */
@@ -117,6 +117,9 @@ typedef struct sddp_stats {
     double gap;        /* remaining defect 1-norm                           */
     double mu;         /* final regularisation                              */
     double expected;   /* last expected reduction -(dV1+dV2)                */
+    double rho;        /* l1 merit weight on the defects at the end (0 while no line search ran with open gaps).  With
+                          cost / alpha / gap / mu it is the whole state the iteration carries from one accepted step to the
+                          next, so a solve cut at max_iters = k can be continued -- or checked step by step (v9)      */
     int    iters;      /* accepted iterations                               */
     int    converged;  /* 1/0                                               */
     int    status;     /* 0 ok (converged = 1), 1 max_iters, 2 regularisation overflow, 3 non-finite cost, 4 line search
@@ -132,7 +135,11 @@ typedef struct sddp_handle sddp_handle;
 int  sddp_abi_version(void);
 int  sddp_model_dims(int model_id, int* nx, int* nu, int* np);
 void sddp_default_options(sddp_options* opts);
-void sddp_default_consts(sddp_model_consts* consts);
+void sddp_default_consts(sddp_model_consts* consts);            /* = sddp_default_consts_for(SDDP_MODEL_SRBD37, ...) */
+/* the synthetic robot as model `model_id` needs it: `feet` holds contact points 0..3 of THAT model --
+ * the line feet (+-0.08, +-0.1, 0) for srbd13 / srbd37 / lip30, the first four sole corners (+-0.08, 0.13 / 0.07, 0) of the
+ * eight-point contact model for srbd61 (prb.py:39-41, :130-131, :153-154).  sddp_create(consts = NULL) uses these.  (v9) */
+int  sddp_default_consts_for(int model_id, sddp_model_consts* consts);
 
 /* replaces pyddp.DdpSolver(nx, nu, f_list, L_list, L_term, opts)                        ddp.py:93-94 */
 int  sddp_create(sddp_handle** out, int model_id, int N, int batch,
@@ -176,9 +183,11 @@ int  sddp_kernel_info(sddp_handle* h, int* wavefronts_per_instance, int* last_wa
  * lane, scratch (spill) bytes per lane, LDS bytes per workgroup (static + dynamic), and how many of its workgroups the device keeps
  * resident per CU (the occupancy query the queue's slot count comes from).  Any pointer may be NULL. */
 int  sddp_kernel_resources(sddp_handle* h, int* vgprs, int* scratch_bytes_per_lane, int* lds_bytes, int* workgroups_per_cu);
-/* Diagnostic for the parity tests: fills the LDS of the device's CUs with NaNs (8 short workgroups per CU, each owning the CU's
- * whole LDS) and waits.  A kernel finds in LDS what the previous one left; after this call a word read before it is written shows
- * up as a NaN in the result instead of passing on a lucky leftover.  Not part of any solve path. */
+/* Supported diagnostic: fills the LDS of the device's CUs with NaNs (8 short workgroups per CU, each owning the CU's whole LDS)
+ * and waits for it.  A kernel finds in LDS what the previous one left; after this call a word read before it is written shows
+ * up as a NaN in the result instead of passing on a lucky leftover.  No solve path calls it (the library reads no environment
+ * variable either): a harness that wants every launch on poisoned LDS calls it before each launch (tests/conftest.py does,
+ * under SDDP_POISON_LDS=1). */
 int  sddp_debug_poison_lds(sddp_handle* h);
 /* results of the last device solve (x, u, stats of the whole batch) to host pointers; waits for the stream */
 int  sddp_fetch(sddp_handle* h, double* x_out, double* u_out, sddp_stats* stats /*[B] or NULL*/);

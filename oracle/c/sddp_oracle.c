@@ -587,6 +587,18 @@ int oracle_solve_batch(int model, const double* cpack, int N, int B, const doubl
     }
     return -1;
 }
+/* -> number of trace records written (ddp_engine.inc: TRACE_W doubles each), or -1 */
+int oracle_trace_width(void) { return TRACE_W; }
+int oracle_solve_trace(int model, const double* cpack, int N, const double* x0, const double* P, double* xs, double* us,
+                       const double* o, double* stats, double* trace, int trace_cap) {
+    switch (model) {
+        case 0: return s13_solve_trace(cpack, N, x0, P, xs, us, o, stats, trace, trace_cap);
+        case 1: return s37_solve_trace(cpack, N, x0, P, xs, us, o, stats, trace, trace_cap);
+        case 2: return l30_solve_trace(cpack, N, x0, P, xs, us, o, stats, trace, trace_cap);
+        case 3: return s61_solve_trace(cpack, N, x0, P, xs, us, o, stats, trace, trace_cap);
+    }
+    return -1;
+}
 int oracle_eval(int model, const double* cpack, const double* x, const double* u, const double* p, int k, int terminal,
                 double* f, double* F, double* H, double* g, double* L) {
     switch (model) {

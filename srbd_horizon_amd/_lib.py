@@ -43,13 +43,16 @@ class SddpModelConsts(C.Structure):
 
 class SddpStats(C.Structure):
     _fields_ = [("cost", C.c_double), ("alpha", C.c_double), ("gap", C.c_double), ("mu", C.c_double),
-                ("expected", C.c_double), ("iters", C.c_int), ("converged", C.c_int), ("status", C.c_int),
+                ("expected", C.c_double), ("rho", C.c_double), ("iters", C.c_int), ("converged", C.c_int), ("status", C.c_int),
                 ("rollouts", C.c_int)]
 
 
-STATS_DTYPE = np.dtype([("cost", "f8"), ("alpha", "f8"), ("gap", "f8"), ("mu", "f8"), ("expected", "f8"),
+STATS_DTYPE = np.dtype([("cost", "f8"), ("alpha", "f8"), ("gap", "f8"), ("mu", "f8"), ("expected", "f8"), ("rho", "f8"),
                         ("iters", "i4"), ("converged", "i4"), ("status", "i4"), ("rollouts", "i4")])
-assert STATS_DTYPE.itemsize == C.sizeof(SddpStats)
+assert STATS_DTYPE.itemsize == C.sizeof(SddpStats) == 64
+# one sddp_stats record seen as words (the zero-copy device views of engine.fetch_device_views)
+STATS_F64_WORDS, STATS_I32_WORDS = 8, 16
+STATS_F64_COST, STATS_I32_ITERS, STATS_I32_STATUS, STATS_I32_ROLLOUTS = 0, 12, 14, 15
 
 _P = C.POINTER
 _dp = _P(C.c_double)
@@ -61,6 +64,7 @@ SYMBOLS = {
     "sddp_model_dims": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "sddp_default_options": (None, [_P(SddpOptions)]),
     "sddp_default_consts": (None, [_P(SddpModelConsts)]),
+    "sddp_default_consts_for": (C.c_int, [C.c_int, _P(SddpModelConsts)]),
     "sddp_set_params": (C.c_int, [_vp, _vp]),
     "sddp_advance": (C.c_int, [_vp, _vp, _vp]),
     "sddp_solve_resident": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -118,42 +122,71 @@ def _newer(target: str, deps) -> bool:
     return os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
 
 
+def _cmd_stamp(obj: str) -> str:
+    return obj + ".cmd"
+
+
+def _fresh(obj: str, deps, cmd) -> bool:
+    """An object is fresh when it is newer than its sources AND was compiled by exactly this command line (flags, defines)."""
+    if not _newer(obj, deps):
+        return False
+    try:
+        return open(_cmd_stamp(obj)).read() == " ".join(cmd)
+    except OSError:
+        return False
+
+
 def build(force: bool = False, verbose: bool = False, only=None) -> str:
     """Compile the HIP library for gfx950 into libsddp_hip.so (in-tree, so it travels to the GPU box): the host API
     (csrc/sddp_api.hip), the queue sort (csrc/sddp_sort.hip) and one object per model build (csrc/sddp_inst.hip x INSTANCES),
-    compiled in parallel and linked.  Objects live in build/obj (git-ignored); only stale ones are recompiled.
-    only: recompile just these model builds (development)."""
+    compiled in parallel and linked.  Objects live in build/obj (git-ignored), each beside a stamp of the command line that
+    made it; stale ones (older than a source or header, or made by another command line) are recompiled.
+    only: recompile just these model builds (development); refuses to link while another object is stale."""
+    import hashlib
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("SDDP_CXXFLAGS", "").split()      # diagnostic builds only (-DSDDP_STAMPS), with SDDP_LIB
-    tag = "" if LIB_PATH.endswith("libsddp_hip.so") and not extra else "_" + str(abs(hash((LIB_PATH, tuple(extra)))) % 10**8)
+    default = LIB_PATH.endswith("libsddp_hip.so") and not extra
+    tag = "" if default else "_" + hashlib.sha1(repr((LIB_PATH, tuple(extra))).encode()).hexdigest()[:10]
     objdir = os.path.join(ROOT, "build", "obj" + tag)
-    os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "sddp.h")]
+    srcs = [os.path.join(CSRC, n + ".hip") for n in ("sddp_api", "sddp_sort", "sddp_inst")]
+    if not force and only is None and not os.path.isdir(objdir) and _newer(LIB_PATH, srcs + hdrs):
+        return LIB_PATH                                      # a shipped library newer than every source: nothing to do
+    os.makedirs(objdir, exist_ok=True)
     base = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC, *extra, "-c"]
     jobs = []
     for name in ("sddp_api", "sddp_sort"):
-        jobs.append((os.path.join(objdir, name + ".o"), os.path.join(CSRC, name + ".hip"), []))
+        src = os.path.join(CSRC, name + ".hip")
+        obj = os.path.join(objdir, name + ".o")
+        jobs.append((obj, src, base + [src, "-o", obj]))
     inst = os.path.join(CSRC, "sddp_inst.hip")
     for fn, model, mname in INSTANCES:
-        jobs.append((os.path.join(objdir, "inst_" + fn + ".o"), inst,
-                     ["-DSDDP_INST_MODEL=" + model, "-DSDDP_INST_FN=ops_" + fn, '-DSDDP_INST_NAME="' + mname + '"', *INSTANCE_FLAGS.get(fn, [])]))
-    todo = []
-    for obj, src, defs in jobs:
+        obj = os.path.join(objdir, "inst_" + fn + ".o")
+        defs = ["-DSDDP_INST_MODEL=" + model, "-DSDDP_INST_FN=ops_" + fn, '-DSDDP_INST_NAME="' + mname + '"', *INSTANCE_FLAGS.get(fn, [])]
+        jobs.append((obj, inst, base + defs + [inst, "-o", obj]))
+    todo, left_stale = [], []
+    for obj, src, cmd in jobs:
         picked = only is not None and any(obj.endswith("inst_" + o + ".o") for o in only)
-        if force or picked or not _newer(obj, [src] + hdrs):
-            if only is not None and not picked and os.path.exists(obj) and not force:
+        if force or picked or not _fresh(obj, [src] + hdrs, cmd):
+            if only is not None and not picked and not force:
+                left_stale.append(os.path.basename(obj))
                 continue
-            todo.append((obj, src, defs))
+            todo.append((obj, src, cmd))
+    if left_stale:
+        raise RuntimeError(f"build(only={only}): {left_stale} are stale too; build without `only` first")
     if not todo and _newer(LIB_PATH, [j[0] for j in jobs]):
         return LIB_PATH
 
     def compile_one(job):
-        obj, src, defs = job
-        cmd = base + defs + [src, "-o", obj]
+        obj, src, cmd = job
         if verbose:
             print(" ".join(cmd), flush=True)
+        if os.path.exists(_cmd_stamp(obj)):
+            os.remove(_cmd_stamp(obj))
         subprocess.run(cmd, check=True)
+        with open(_cmd_stamp(obj), "w") as f:
+            f.write(" ".join(cmd))
 
     workers = max(1, min(len(todo), int(os.environ.get("SDDP_BUILD_JOBS", str(os.cpu_count() or 4)))))
     if todo:
@@ -186,7 +219,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.sddp_abi_version() != 8:
+    if lib.sddp_abi_version() != 9:
         raise RuntimeError("libsddp_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -202,9 +235,14 @@ def default_options(**over) -> SddpOptions:
     return o
 
 
-def default_consts(**over) -> SddpModelConsts:
+def default_consts(model: str | None = None, **over) -> SddpModelConsts:
+    """The synthetic robot as `model` needs it (sddp_default_consts_for: srbd61's `feet` are the first four sole corners of the
+    eight-point contact model); model None = the line-foot robot of sddp_default_consts."""
     c = SddpModelConsts()
-    load().sddp_default_consts(C.byref(c))
+    if model is None:
+        load().sddp_default_consts(C.byref(c))
+    else:
+        check(load().sddp_default_consts_for(MODEL_IDS[model], C.byref(c)))
     set_consts(c, **over)
     return c
 

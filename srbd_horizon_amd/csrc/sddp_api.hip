@@ -16,8 +16,6 @@
 #include "sddp_kernels_host.hpp"
 #include "sddp_sort.hpp"
 
-static bool poison_every_launch();   // SDDP_POISON_LDS=1: test runs only (defined beside sddp_debug_poison_lds)
-
 using namespace sddp;
 
 // the model builds of the library (sddp_inst.hip, one translation unit each; srbd_horizon_amd/_lib.py INSTANCES)
@@ -171,15 +169,21 @@ void sddp_default_options(sddp_options* o) {
     o->max_slots = 0;
 }
 
-void sddp_default_consts(sddp_model_consts* c) {
-    if (!c) return;
+void sddp_default_consts(sddp_model_consts* c) { sddp_default_consts_for(SDDP_MODEL_SRBD37, c); }
+
+int sddp_default_consts_for(int model_id, sddp_model_consts* c) {
+    if (!c) return SDDP_ERR_ARG;
+    if (!model_ops(model_id)) return SDDP_ERR_MODEL;
     std::memset(c, 0, sizeof(*c));
     c->m = 40.0;
     const double I[9] = {2.0, 0.03, -0.02, 0.03, 1.8, 0.04, -0.02, 0.04, 0.6};
     std::memcpy(c->I, I, sizeof(I));
     c->com[0] = 0.0; c->com[1] = 0.0; c->com[2] = 0.88;
+    // contact points 0..3: the line feet (launch:24-25), or the first four sole corners of contact_model = 4 (prb.py:39-41) --
+    // the points d_initial_1/2 of prb.py:153-154 name whatever nc is
     const double feet[12] = {0.08, 0.1, 0.0, -0.08, 0.1, 0.0, 0.08, -0.1, 0.0, -0.08, -0.1, 0.0};
-    std::memcpy(c->feet, feet, sizeof(feet));
+    const double feet8[12] = {0.08, 0.13, 0.0, -0.08, 0.13, 0.0, 0.08, 0.07, 0.0, -0.08, 0.07, 0.0};
+    std::memcpy(c->feet, model_id == SDDP_MODEL_SRBD61 ? feet8 : feet, sizeof(feet));
     c->dt = 0.05;
     c->force_scaling = 1000.0;
     c->r_tracking_gain = 1e3; c->rdot_tracking_gain = 1e4; c->w_tracking_gain = 1e4; c->rel_pos_gain = 1e4;
@@ -193,6 +197,7 @@ void sddp_default_consts(sddp_model_consts* c) {
     c->bound_barrier_weight = 0.0;           // off: the reference's bound barriers are commented out (ddp.py:203-208)
     c->bound_barrier_sharpness = 6.0;        // exp_parameter, ddp.py:182
     for (int i = 0; i < 64; ++i) { c->lower[i] = -HUGE_VAL; c->upper[i] = HUGE_VAL; }
+    return SDDP_OK;
 }
 
 const char* sddp_last_error(const sddp_handle* h) { return h ? h->err.c_str() : create_error().c_str(); }
@@ -226,7 +231,7 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (!h) return fail(nullptr, SDDP_ERR_NOMEM, "out of host memory");
     h->model_id = model_id; h->N = N; h->B = batch; h->d = d; h->ops = ops; h->bar = bar; h->so2 = so2;
     if (opts) h->opts = *opts; else sddp_default_options(&h->opts);
-    if (consts) h->consts = *consts; else sddp_default_consts(&h->consts);
+    if (consts) h->consts = *consts; else sddp_default_consts_for(model_id, &h->consts);
     int rc = validate_options(h, h->opts);
     if (rc != SDDP_OK) { create_error() = h->err; delete h; return rc; }
     h->dc = make_dev_consts(h->consts);
@@ -420,7 +425,6 @@ int sddp_solve_range_device(sddp_handle* h, const double* d_params, int first, i
     if (!d_params) return fail(h, SDDP_ERR_ARG, "params is NULL");
     if (first < 0 || count < 1 || first > h->B - count) return fail(h, SDDP_ERR_ARG, "instance range outside the batch");
     SolveArgs a = make_args(h, d_params);
-    if (poison_every_launch()) sddp_debug_poison_lds(h);
     rc = h->ops->launch_solve(h, a, first, count);
     return rc;
 }
@@ -456,13 +460,6 @@ int sddp_kernel_resources(sddp_handle* h, int* vgprs, int* scratch_bytes_per_lan
     if (lds_bytes) *lds_bytes = h->last_lds + int(at.sharedSizeBytes);
     if (workgroups_per_cu) *workgroups_per_cu = h->last_per_cu;
     return SDDP_OK;
-}
-
-// SDDP_POISON_LDS=1 (test runs only): every solve / sweep / pass launch of the process is preceded by sddp_debug_poison_lds, so the
-// whole GPU suite can be run on NaN-filled LDS (tests/test_gpu_lds_poison.py covers the kernels; this covers every path to them).
-static bool poison_every_launch() {
-    static const bool on = [] { const char* e = getenv("SDDP_POISON_LDS"); return e && e[0] == '1'; }();
-    return on;
 }
 
 int sddp_debug_poison_lds(sddp_handle* h) {
@@ -721,7 +718,7 @@ int sddp_kernel_time_stats(sddp_handle* h, double* sum_ms, long long* count, int
 int sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk, const int* k, const double* x,
                     const double* u, const double* p, double* f_out, double* F_out, double* H_out, double* g_out, double* L_out) {
     sddp_model_consts cc;
-    if (consts) cc = *consts; else sddp_default_consts(&cc);
+    if (consts) cc = *consts; else if (sddp_default_consts_for(model_id, &cc) != SDDP_OK) return SDDP_ERR_MODEL;
     if (!model_ops(model_id)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
     const bool bar = (cc.friction_barrier_weight > 0.0 || cc.bound_barrier_weight > 0.0) && !single_build(model_id);
     const ModelOps* ops = model_ops(model_id, bar, false);
@@ -775,7 +772,6 @@ int sddp_backward(sddp_handle* h, const double* params, double mu, double* gains
     HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     SolveArgs a = make_args(h, h->P);
     a.mu = mu;
-    if (poison_every_launch()) sddp_debug_poison_lds(h);
     rc = h->ops->launch_backward(h, a);
     if (rc != SDDP_OK) return rc;
     h->gains_by_instance = true;
@@ -800,7 +796,6 @@ int sddp_forward(sddp_handle* h, const double* params, double alpha, double* x_o
     HIP_TRY(h, hipMemcpyAsync(h->P, params, h->n_p() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     SolveArgs a = make_args(h, h->P);
     a.alpha = alpha;
-    if (poison_every_launch()) sddp_debug_poison_lds(h);
     rc = h->ops->launch_forward(h, a);
     if (rc != SDDP_OK) return rc;
     if (x_out) HIP_TRY(h, hipMemcpyAsync(x_out, h->xn, h->n_x() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -1278,7 +1278,7 @@ __device__ __forceinline__ void solve_instance_mw(const SolveArgs& A, double* s,
 #endif
     if (tid == 0) {
         sddp_stats st;
-        st.cost = J; st.alpha = alpha; st.gap = gap; st.mu = mu; st.expected = expected;
+        st.cost = J; st.alpha = alpha; st.gap = gap; st.mu = mu; st.expected = expected; st.rho = rho;
         st.iters = iters; st.converged = converged; st.status = status; st.rollouts = rollouts;
         A.stats[b] = st;
         A.hist[b] = iters;

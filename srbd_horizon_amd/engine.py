@@ -20,7 +20,7 @@ class DdpEngine:
         self.N, self.B = int(N), int(batch)
         self.nx, self.nu, self.np_ = _lib.model_dims(model)
         self.opts = _lib.default_options(**(opts or {}))
-        self.consts = _lib.default_consts(**(consts or {}))
+        self.consts = _lib.default_consts(model, **(consts or {}))
         h = C.c_void_p()
         _lib.check(self.lib.sddp_create(C.byref(h), _lib.MODEL_IDS[model], self.N, self.B,
                                         C.byref(self.opts), C.byref(self.consts)))
@@ -190,8 +190,9 @@ class DdpEngine:
         return p.value, n.value
 
     def fetch_device_views(self):
-        """Zero-copy torch views of the handle's HBM buffers: x [B,N+1,nx], u [B,N,nu], stats as f64 [B,7] and i32 [B,14]
-        (sddp_stats: cost, alpha, gap, mu, expected | iters, converged, status, rollouts)."""
+        """Zero-copy torch views of the handle's HBM buffers: x [B,N+1,nx], u [B,N,nu], stats as f64 [B,8] and i32 [B,16]
+        (sddp_stats: cost, alpha, gap, mu, expected, rho | iters, converged, status, rollouts = i32 words 12..15;
+        _lib.STATS_I32_ITERS etc.)."""
         import torch
         dev = torch.device("cuda", torch.cuda.current_device())
 
@@ -204,8 +205,8 @@ class DdpEngine:
         ps, _ = self.device_buffer(2)
         x = torch.as_tensor(_Dev(px, (self.B, self.N + 1, self.nx), "<f8"), device=dev)
         u = torch.as_tensor(_Dev(pu, (self.B, self.N, self.nu), "<f8"), device=dev)
-        sf = torch.as_tensor(_Dev(ps, (self.B, 7), "<f8"), device=dev)
-        si = torch.as_tensor(_Dev(ps, (self.B, 14), "<i4"), device=dev)
+        sf = torch.as_tensor(_Dev(ps, (self.B, _lib.STATS_F64_WORDS), "<f8"), device=dev)
+        si = torch.as_tensor(_Dev(ps, (self.B, _lib.STATS_I32_WORDS), "<i4"), device=dev)
         return x, u, sf, si
 
     def fetch(self):
@@ -262,7 +263,7 @@ class DdpEngine:
         return a.value, b.value, c.value
 
     def poison_lds(self):
-        """Diagnostic (parity tests): fill the LDS of every CU with NaNs, so the next launch cannot pass on what an earlier kernel
+        """Diagnostic (include/sddp.h): fill the LDS of every CU with NaNs, so the next launch cannot pass on what an earlier kernel
         happened to leave in a word it reads before writing."""
         self._chk(self.lib.sddp_debug_poison_lds(self.h))
 
@@ -292,7 +293,7 @@ def eval_knots(model: str, N: int, k, x, u, p, consts: dict | None = None):
     x = np.ascontiguousarray(x, dtype=np.float64).reshape(nk, nx)
     u = np.ascontiguousarray(u, dtype=np.float64).reshape(nk, nu)
     p = np.ascontiguousarray(p, dtype=np.float64).reshape(nk, npar)
-    cst = _lib.default_consts(**(consts or {}))
+    cst = _lib.default_consts(model, **(consts or {}))
     f = np.empty((nk, nx)); F = np.empty((nk, nx, nz)); H = np.empty((nk, nz, nz)); g = np.empty((nk, nz)); L = np.empty(nk)
     _lib.check(lib.sddp_eval_knots(_lib.MODEL_IDS[model], C.byref(cst), int(N), nk, _lib.ptr(k), _lib.ptr(x), _lib.ptr(u),
                                    _lib.ptr(p), _lib.ptr(f), _lib.ptr(F), _lib.ptr(H), _lib.ptr(g), _lib.ptr(L)))

@@ -24,6 +24,7 @@ that stream here).
 """
 from __future__ import annotations
 
+from . import _lib
 from . import dist as sdist
 
 
@@ -82,7 +83,7 @@ class FleetQueue:
             import torch.distributed as dist
             k = self._k
             self._wait(k)                                                    # this pair's previous collective (two flushes ago)
-            local = sdist.pack_records_into(self._pack[k][:n], self.x[:n], self.u[:n], self.sf[:n, 0], self.si[:n, 10])   # cost, iters
+            local = sdist.pack_records_into(self._pack[k][:n], self.x[:n], self.u[:n], self.sf[:n, _lib.STATS_F64_COST], self.si[:n, _lib.STATS_I32_ITERS])
             self._work[k] = dist.all_gather_into_tensor(self._out[k][:self.world * n], local, async_op=True)
             self._n[k] = n
             self.gather_bytes += local.numel() * local.element_size()

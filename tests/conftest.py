@@ -29,6 +29,35 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+# SDDP_POISON_LDS=1: the whole GPU suite on NaN-filled LDS.  The hook lives HERE, not in the library (which reads no environment
+# variable): every entry point that launches a solve / sweep / pass kernel is wrapped so that sddp_debug_poison_lds runs first.
+_LAUNCHING = ("sddp_solve", "sddp_solve_device", "sddp_solve_range_device", "sddp_solve_resident", "sddp_solve_resident_first",
+              "sddp_backward", "sddp_forward")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _poison_lds_before_every_launch():
+    if os.environ.get("SDDP_POISON_LDS") != "1" or not _has_gpu():
+        yield
+        return
+    from srbd_horizon_amd import _lib
+    lib = _lib.load()
+    originals = {}
+    for name in _LAUNCHING:
+        fn = getattr(lib, name)
+        originals[name] = fn
+
+        def wrapped(h, *args, _fn=fn):
+            rc = lib.sddp_debug_poison_lds(h)
+            if rc != 0:
+                return rc
+            return _fn(h, *args)
+        setattr(lib, name, wrapped)
+    yield
+    for name, fn in originals.items():
+        setattr(lib, name, fn)
+
+
 def report_parity(record_property, key: str, **counts):
     """Parity bookkeeping that survives `pytest -q`: the counts go into the junit properties of the test AND into a warning, which
     pytest lists in its warnings summary (so the driver's record of the GPU run shows how far from its allowance a test ran)."""

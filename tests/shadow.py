@@ -1,0 +1,188 @@
+"""One-step shadowing: the parity statement that survives a chaotic iteration.
+
+Some hard instances crawl for 50-100 iterations along a path on which every rollout amplifies a perturbation (the cost moves
+by up to three orders of magnitude more than the iterate did).  Two correct implementations that differ only in rounding -- the
+GPU kernel and the C oracle, or two builds of the C oracle itself (-ffp-contract=off / fast) -- then drift apart smoothly, with
+the SAME step lengths, from 1e-16 to 1e-3 relative, and only then take different step lengths and iteration counts.  Comparing
+such solves end to end says nothing about either.  What can be checked, and is checked here for EVERY accepted step of the engine
+under test: take its iterate k (trajectory and the carried state: merit weight, regularisation, second-order switch, open /
+closed gaps), let the oracle do ONE iteration from it, and compare with the engine's iterate k + 1 -- same step length, same
+cost, same trajectory.  One step amplifies rounding by at most the one-step factor, so the tolerance stays tight and a real
+defect of the kernel (a wrong gain, a wrong candidate, a wrong acceptance test) cannot hide behind "chaos".
+"""
+import numpy as np
+
+from oracle import cport, ddp as oddp
+
+
+def shadow_one_instance(cst, opts: dict, x0, P, states, model="srbd13", variant=None):
+    """states[k] = dict(x, u, cost, alpha, gap, mu, rho, iters, status, converged) of the engine under test cut at max_iters = k
+    (k = 0: the warm start).  -> list of per-step records and the end-of-solve record."""
+    a0 = opts.get("alpha_0", 1.0)
+    so = opts.get("second_order", 1)
+    out = []
+    K = len(states) - 1
+    for k in range(K):
+        s, t = states[k], states[k + 1]
+        if t["iters"] != k + 1:                # the engine stopped before an accepted step k + 1
+            break
+        resume = dict(rho=s["rho"], theta=1.0 if (k > 0 and so and s["alpha"] == a0) else 0.0, closed=(k > 0 and s["gap"] == 0.0),
+                      mu=s["mu"])
+        o1 = oddp.DdpOptions(**dict(opts, max_iters=1))
+        xo, uo, st, tr = cport.solve_trace(cst, o1, x0, P, s["x"], s["u"], model=model, variant=variant, resume=resume)
+        J = max(abs(t["cost"]), 1e-300)
+        rec = dict(k=k + 1, alpha_engine=float(t["alpha"]), alpha_oracle=float(st[3]), oracle_iters=int(st[1]),
+                   rel_cost=abs(st[0] - t["cost"]) / J,
+                   linf_x=float(np.max(np.abs(xo - t["x"]))), linf_u=float(np.max(np.abs(uo - t["u"]))),
+                   scale_x=float(np.max(np.abs(t["x"]))), scale_u=float(np.max(np.abs(t["u"]))))
+        # how close to a tie the decision was: the smallest |Armijo margin| / |J| over the candidates the oracle tried
+        if tr:
+            m = np.abs(tr[-1]["margin"]) / max(abs(tr[-1]["J"]), 1e-300)
+            m = m[np.isfinite(m)]
+            rec["min_margin_rel"] = float(np.min(m)) if m.size else float("inf")
+        out.append(rec)
+    return out
+
+
+def engine_states_from_oracle(cst, opts: dict, x0, P, xs, us, model="srbd13", variant=None, kmax=None):
+    """The `states` list of shadow_one_instance produced by a CPU build of the oracle (stand-in for the GPU engine in the CPU test)."""
+    states = []
+    kmax = opts["max_iters"] if kmax is None else kmax
+    for k in range(kmax + 1):
+        o = oddp.DdpOptions(**dict(opts, max_iters=k))
+        x, u, st = cport.solve_batch(cst, o, x0[None], P[None], xs[None], us[None], model=model, variant=variant)
+        states.append(dict(x=x[0], u=u[0], cost=st[0, 0], iters=int(st[0, 1]), converged=int(st[0, 2]), alpha=st[0, 3], gap=st[0, 4],
+                           mu=st[0, 5], status=int(st[0, 6]), rho=st[0, 7]))
+        if states[-1]["iters"] < k:
+            break
+    return states
+
+
+def summarize(records):
+    """worst one-step deviations over a list of per-step records"""
+    if not records:
+        return dict(steps=0)
+    return dict(steps=len(records),
+                alpha_mismatch=[r["k"] for r in records if r["alpha_engine"] != r["alpha_oracle"] or r["oracle_iters"] != 1],
+                max_rel_cost=max(r["rel_cost"] for r in records),
+                max_rel_x=max(r["linf_x"] / max(r["scale_x"], 1e-300) for r in records),
+                max_rel_u=max(r["linf_u"] / max(r["scale_u"], 1e-300) for r in records),
+                min_margin_rel=min(r.get("min_margin_rel", np.inf) for r in records))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# whole batches: GPU engine vs C oracle, with every instance on another path explained step by step
+# ---------------------------------------------------------------------------------------------------------------------------------
+ONE_STEP_COST_RTOL = 1e-3      # worst single step (the two CPU builds of the oracle reach 1e-5 against each other on such steps)
+ONE_STEP_MEDIAN_RTOL = 1e-7    # median step of an instance
+
+
+def engine_states(model, N, opts, consts, x0, P, xs, us, kmax):
+    """states[b][k] of the HIP engine for the D instances given, cut at max_iters = 0..kmax (D instances per launch)."""
+    from srbd_horizon_amd.engine import DdpEngine
+    D = x0.shape[0]
+    eng = DdpEngine(model, N, D, opts=dict(opts, max_iters=0), consts=consts)
+    eng.set_initial_state(x0)
+    states = [[] for _ in range(D)]
+    for k in range(kmax + 1):
+        eng.set_options(max_iters=k)
+        eng.set_x_warmstart(xs); eng.set_u_warmstart(us)
+        x, u = eng.solve(P)
+        st = eng.stats
+        for b in range(D):
+            states[b].append(dict(x=x[b].copy(), u=u[b].copy(), cost=float(st["cost"][b]), iters=int(st["iters"][b]),
+                                  converged=int(st["converged"][b]), alpha=float(st["alpha"][b]), gap=float(st["gap"][b]),
+                                  mu=float(st["mu"][b]), status=int(st["status"][b]), rho=float(st["rho"][b])))
+    eng.close()
+    return states
+
+
+def first_split(states, trace):
+    """First accepted step at which the engine (states, or a second oracle line-search trace) and a full oracle run (its
+    line-search trace) take different step lengths, and how far their costs had drifted apart BEFORE that step.
+    -> dict or None (same step lengths throughout)."""
+    acc = [r for r in trace if r["alpha"] > 0.0]
+    if states and "J_new" in states[0]:                                     # a trace: J before step k + 1, alpha of step k + 1
+        other = [r for r in states if r["alpha"] > 0.0]
+        seq = [(r["J"], r["alpha"]) for r in other]
+    else:
+        seq = [(states[k]["cost"], states[k + 1]["alpha"]) for k in range(len(states) - 1) if states[k + 1]["iters"] == k + 1]
+    for k in range(min(len(seq), len(acc))):
+        if seq[k][1] != acc[k]["alpha"]:
+            J = max(abs(acc[k]["J"]), 1e-300)
+            return dict(step=k + 1, alpha_engine=float(seq[k][1]), alpha_oracle=float(acc[k]["alpha"]),
+                        drift_before=float(abs(seq[k][0] - acc[k]["J"]) / J))
+    return None
+
+
+def explain_divergent(model, N, opts, engine_over, consts, cst, batch, idx):
+    """For the instances idx of `batch` (those whose GPU iteration count differs from the oracle's): one-step shadowing of the
+    whole GPU path, the first split against the full oracle path, and the first split of the second CPU build of the oracle
+    (-ffp-contract=fast) against the first.  opts: the algorithm's options (both sides), engine_over: scheduling options of the
+    engine.  -> list of records (one per instance)."""
+    idx = np.asarray(idx)
+    kmax = opts["max_iters"]
+    sub = {k: batch[k][idx] for k in ("x0", "params", "xs", "us")}
+    gs = engine_states(model, N, dict(opts, **engine_over), consts, sub["x0"], sub["params"], sub["xs"], sub["us"], kmax)
+    out = []
+    for j, b in enumerate(idx):
+        a = (cst, oddp.DdpOptions(**opts), sub["x0"][j], sub["params"][j], sub["xs"][j], sub["us"][j])
+        xo, uo, so, tr_off = cport.solve_trace(*a, model=model)
+        xf, uf, sf, tr_fast = cport.solve_trace(*a, model=model, variant="fast")
+        steps = shadow_one_instance(cst, opts, sub["x0"][j], sub["params"][j], gs[j], model=model)
+        end = gs[j][kmax]
+        rec = dict(instance=int(b), gpu_iters=end["iters"], oracle_iters=int(so[1]), oracle_fast_iters=int(sf[1]),
+                   gpu_status=end["status"], oracle_status=int(so[6]),
+                   shadow=summarize(steps), median_rel_cost=float(np.median([r["rel_cost"] for r in steps])) if steps else 0.0,
+                   split_gpu=first_split(gs[j], tr_off), split_cpu_fast=first_split(tr_fast, tr_off),
+                   end_linf=float(max(np.max(np.abs(end["x"] - xo)), np.max(np.abs(end["u"] - uo)))),
+                   end_rel_cost=float(abs(end["cost"] - so[0]) / max(abs(so[0]), 1e-300)))
+        out.append(rec)
+    return out
+
+
+def assert_shadowed(rec):
+    """Every accepted step of the GPU path is the oracle's step from the same iterate."""
+    s = rec["shadow"]
+    assert s["steps"] == rec["gpu_iters"], rec
+    # a step length may differ only on a genuine tie of the Armijo test (margin at rounding level); none has been seen
+    assert not s["alpha_mismatch"] or s["min_margin_rel"] <= 1e-9, rec
+    assert s["max_rel_cost"] <= ONE_STEP_COST_RTOL, rec
+    assert rec["median_rel_cost"] <= ONE_STEP_MEDIAN_RTOL, rec
+
+
+def check_batch(model, N, batch, opts, engine_over, cst, threads=16):
+    """GPU solve of a whole batch through the queue vs the C oracle (both CPU builds).  -> dict(x, u, st, xo, uo, so, same,
+    explained: the records of explain_divergent for every instance with another iteration count, n_cpu_pair: instances on which
+    the two CPU builds of the oracle take different iteration counts)."""
+    from srbd_horizon_amd.engine import DdpEngine
+    B = batch["x0"].shape[0]
+    eng = DdpEngine(model, N, B, opts=dict(opts, **engine_over), consts=batch["consts"])
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    st = eng.stats.copy()
+    qi = eng.queue_info()
+    eng.close()
+    o = oddp.DdpOptions(**opts)
+    xo, uo, so = cport.solve_batch(cst, o, batch["x0"], batch["params"], batch["xs"], batch["us"], threads=threads, model=model)
+    _, _, sf = cport.solve_batch(cst, o, batch["x0"], batch["params"], batch["xs"], batch["us"], threads=threads, model=model,
+                                 variant="fast")
+    it_o = so[:, 1].astype(int)
+    same = st["iters"] == it_o
+    idx = np.nonzero(~same)[0]
+    explained = explain_divergent(model, N, opts, engine_over, batch["consts"], cst, batch, idx) if idx.size else []
+    return dict(x=x, u=u, st=st, xo=xo, uo=uo, so=so, same=same, explained=explained, queue_info=qi,
+                n_cpu_pair=int((sf[:, 1] != so[:, 1]).sum()), cpu_pair_idx=np.nonzero(sf[:, 1] != so[:, 1])[0])
+
+
+def parity_record(res):
+    """The PARITY-COUNT payload of a check_batch result (tests/conftest.py report_parity)."""
+    ex = res["explained"]
+    return dict(differ=len(ex), cpu_pair_differ=res["n_cpu_pair"],
+                both=len(set(r["instance"] for r in ex) & set(res["cpu_pair_idx"].tolist())),
+                instances=[dict(i=r["instance"], it=(r["gpu_iters"], r["oracle_iters"], r["oracle_fast_iters"]),
+                                split=(r["split_gpu"] or {}).get("step"), drift=(r["split_gpu"] or {}).get("drift_before"),
+                                cpu_split=(r["split_cpu_fast"] or {}).get("step"), cpu_drift=(r["split_cpu_fast"] or {}).get("drift_before"),
+                                step_max=r["shadow"].get("max_rel_cost"), step_med=r["median_rel_cost"],
+                                amis=len(r["shadow"].get("alpha_mismatch", [])), end_linf=r["end_linf"],
+                                status=(r["gpu_status"], r["oracle_status"])) for r in ex])

@@ -26,7 +26,7 @@ def test_header_symbols_are_all_bound_and_exported(lib):
 
 
 def test_struct_layouts_and_dims(lib):
-    assert lib.sddp_abi_version() == 8
+    assert lib.sddp_abi_version() == 9
     assert _lib.model_dims("srbd13") == (13, 6, 19)
     assert _lib.model_dims("srbd37") == (37, 24, 19)
     assert _lib.model_dims("lip30") == (30, 15, 11)
@@ -37,7 +37,10 @@ def test_struct_layouts_and_dims(lib):
     assert (o.max_iters, o.alpha_0, o.alpha_converge_threshold, o.line_search_decrease_factor, o.beta) == (100, 1.0, 1e-1, 0.5, 1e-4)
     c = _lib.default_consts()
     assert c.force_scaling == 1000.0 and c.dt == 0.05 and c.inertia_mode == 0 and abs(c.com[2] - 0.88) < 1e-15
-    assert C.sizeof(_lib.SddpStats) == 56
+    assert C.sizeof(_lib.SddpStats) == 64                                 # v9: + rho
+    # model-aware defaults (v9): srbd61's contact points 0..3 are the first four sole corners, not the line feet
+    assert list(_lib.default_consts("srbd61").feet)[:6] == [0.08, 0.13, 0.0, -0.08, 0.13, 0.0]
+    assert list(_lib.default_consts("srbd37").feet) == list(c.feet) == list(_lib.default_consts("srbd13").feet)
 
 
 def test_set_consts_resets_the_tail_of_the_bounds():

@@ -28,8 +28,8 @@ class OracleEngine:
         self.x = torch.zeros(B, N + 1, NX, dtype=torch.float64)
         self.u = torch.zeros(B, N, NU, dtype=torch.float64)
         self.stats = np.zeros(B, dtype=_lib.STATS_DTYPE)
-        self.sf = torch.from_numpy(self.stats.view(np.float64).reshape(B, 7))
-        self.si = torch.from_numpy(self.stats.view(np.int32).reshape(B, 14))
+        self.sf = torch.from_numpy(self.stats.view(np.float64).reshape(B, _lib.STATS_F64_WORDS))
+        self.si = torch.from_numpy(self.stats.view(np.int32).reshape(B, _lib.STATS_I32_WORDS))
 
     def load_range_device(self, first, count, x0=None, x=None, u=None):
         s = slice(first, first + count)

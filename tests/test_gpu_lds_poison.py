@@ -3,7 +3,7 @@ left behind, so such a read passes or fails by the order the tests ran in (round
 the never-written pad column of its staged gain rows by a zero of x - x_k -- a NaN when the leftover was one).
 sddp_debug_poison_lds fills every CU's LDS with NaNs; each single-phase kernel and the fused solve of every model then has to return
 what it returns on clean LDS, bit for bit.  (The whole GPU suite can be run the same way: `SDDP_POISON_LDS=1 python -m pytest tests -m gpu`
-poisons the LDS before every solve / sweep / pass launch of the process -- round 4: 113 passed.)"""
+poisons the LDS before every solve / sweep / pass launch of the process, through a wrapper in tests/conftest.py.)"""
 import numpy as np
 import pytest
 

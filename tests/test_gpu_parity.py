@@ -17,7 +17,6 @@ from srbd_horizon_amd.engine import DdpEngine, eval_knots
 pytestmark = pytest.mark.gpu
 
 MODELS = ["srbd13", "srbd37", "lip30"]
-BENCH_BATCH_ALLOWED = 3       # instances of the 1024 of the bench batch that may take another iteration count than the C oracle
 
 
 def _oracle_model(name, consts=None):
@@ -371,40 +370,17 @@ def test_whole_bench_batch_matches_the_c_oracle(record_property):
     """All 1024 instances of the bench batch (BASELINE configs[2]) against the plain-C restatement of the oracle
     (oracle/c, pinned to the numpy oracle by tests/test_oracle_c.py): same iteration count and, at the north_star tolerance
     (1e-4 l-inf), the same trajectory -- stragglers included (up to 93 iterations, step lengths down to 2^-9, i.e. the
-    line-search path whose winner is not one of the kept candidates)."""
-    from oracle import cport
+    line-search path whose winner is not one of the kept candidates).  An instance on another path is explained step by step
+    (tests/shadow.py); the full set of instances bench.py times is tests/test_gpu_divergence.py."""
+    from tests import shadow
+    from tests.test_gpu_divergence import assert_batch
     N, B = 30, 1024
     batch = workload.make_batch("srbd13", N, np.arange(B))
-    eng = DdpEngine("srbd13", N, B, opts=_opts())
-    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
-    x, u = eng.solve(batch["params"])
-    st = eng.stats.copy()
-    xo, uo, so = cport.solve_batch(omodels.RobotConsts(**batch["consts"]), _oracle_opts(), batch["x0"], batch["params"],
-                                   batch["xs"], batch["us"], threads=8)
-    it_o = so[:, 1].astype(int)
-    same = st["iters"] == it_o
-    print(f"bench batch: {int((~same).sum())} of {B} instances with a different iteration count than the C oracle "
-          f"(GPU {st['iters'][~same].tolist()} oracle {it_o[~same].tolist()}); max l-inf x {np.max(np.abs(x[same] - xo[same])):.2e}")
-    from tests.conftest import report_parity
-    report_parity(record_property, "bench_batch_1024", differ=int((~same).sum()), allowed=BENCH_BATCH_ALLOWED, gpu_iters=st["iters"][~same].tolist(),
-                  oracle_iters=it_o[~same].tolist())
-    # chaotic early iterations of a few hard instances may pick another step length on a last-bit difference.  The allowance is
-    # what the shipped build shows (PARITY-COUNT in the warnings summary of the GPU run) + 50 %, not a round percentage
-    assert int((~same).sum()) <= BENCH_BATCH_ALLOWED, f"{(~same).sum()} instances with a different iteration count"
+    res = shadow.check_batch("srbd13", N, batch, dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3), {},
+                             omodels.RobotConsts(**batch["consts"]), threads=8)
+    st = res["st"]
     assert st["iters"].max() >= 60 and st["rollouts"].max() > st["iters"].max()       # the fallback path did run
-    ex = np.max(np.abs(x[same] - xo[same]), axis=(1, 2))
-    eu = np.max(np.abs(u[same] - uo[same]), axis=(1, 2))
-    assert ex.max() <= 1e-4 and eu.max() <= 1e-4, (ex.max(), eu.max())
-    np.testing.assert_allclose(st["cost"][same], so[same, 0], rtol=1e-8)
-    np.testing.assert_array_equal(st["converged"][same], so[same, 2].astype(int))
-    # the instances on another path are not dropped from the check: finite, same convergence flag, same optimum
-    d = ~same
-    assert np.all(np.isfinite(x[d])) and np.all(np.isfinite(u[d]))
-    np.testing.assert_array_equal(st["converged"][d], so[d, 2].astype(int))
-    np.testing.assert_allclose(st["cost"][d], so[d, 0], rtol=1e-5)
-    for b in np.nonzero(d & (so[:, 2] == 1) & (st["converged"] == 1))[0]:     # ... and, converged on both sides, the same trajectory
-        e = max(np.max(np.abs(x[b] - xo[b])), np.max(np.abs(u[b] - uo[b])))
-        assert e <= 1e-4, f"instance {b}: GPU {st['iters'][b]} / oracle {it_o[b]} iterations, both converged, linf {e:.3e}"
+    assert_batch(res, "bench_batch_1024", record_property)
 
 
 @pytest.mark.parametrize("name,N,B", [("srbd13", 1, 3), ("srbd13", 2, 1), ("srbd13", 100, 2), ("lip30", 1, 2), ("srbd37", 2, 2),

@@ -21,6 +21,27 @@ def _opts(**over):
     return o
 
 
+def test_default_constants_are_the_eight_point_robot():
+    """sddp_create(consts = NULL) / DdpEngine("srbd61") without constants must solve the problem its own workload and oracle
+    describe: contact points 0..3 = the first four sole corners of the eight-point model (sddp_default_consts_for, ABI v9), not the
+    line feet of srbd37 (the rel_pos targets d_initial_1/2 silently differed)."""
+    N, seeds = 20, np.arange(6)
+    batch = workload.make_batch(NAME, N, seeds)
+    eng = DdpEngine(NAME, N, len(seeds), opts=_opts())                       # no consts
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    xo, uo, so = cport.solve_batch(omodels.make_model(NAME).cst, oddp.DdpOptions(**_opts()), batch["x0"], batch["params"], batch["xs"],
+                                   batch["us"], threads=4, model=NAME)
+    np.testing.assert_array_equal(eng.stats["iters"], so[:, 1].astype(int))
+    assert eng.stats["converged"].all()
+    assert np.max(np.abs(x - xo)) <= 1e-6 and np.max(np.abs(u - uo)) <= 1e-6
+    np.testing.assert_allclose(eng.stats["cost"], so[:, 0], rtol=1e-9)
+    ex = DdpEngine(NAME, N, len(seeds), opts=_opts(), consts=batch["consts"])      # the builder's explicit constants: the same problem
+    ex.set_initial_state(batch["x0"]); ex.set_x_warmstart(batch["xs"]); ex.set_u_warmstart(batch["us"])
+    x2, u2 = ex.solve(batch["params"])
+    np.testing.assert_array_equal(x2, x); np.testing.assert_array_equal(u2, u)
+
+
 @pytest.mark.parametrize("imode,lever", [(0, 1.0), (1, -1.0)])
 def test_eval_knots_matches_oracle(imode, lever):
     N = 20
