@@ -15,31 +15,60 @@ import numpy as np
 from oracle import cport, ddp as oddp
 
 
-def shadow_one_instance(cst, opts: dict, x0, P, states, model="srbd13", variant=None):
+PROBE_REL = 1e-12      # relative size (per entry) of the perturbations of the iterate
+SENS_DRAWS = 3         # perturbed repeats of every step: the oracle's own sensitivity there
+PROBE_DRAWS = 16       # more of them where engine and oracle choose different step lengths
+SENS_FACTOR = 30.0     # a step may deviate by this multiple of the oracle's own response to a PROBE_REL perturbation ...
+ONE_STEP_FLOOR = 1e-9  # ... or by this much (relative cost), whichever is larger
+ONE_STEP_MEDIAN_RTOL = 1e-7    # and the median step of an instance by no more than this
+
+
+def _one_step(cst, o1, x0, P, x, u, resume, model, variant=None):
+    xo, uo, st, tr = cport.solve_trace(cst, o1, x0, P, x, u, model=model, variant=variant, resume=resume)
+    return xo, uo, st, tr, (float(st[3]) if int(st[1]) == 1 else 0.0)      # step length taken (0.0: line search exhausted)
+
+
+def shadow_one_instance(cst, opts: dict, x0, P, states, model="srbd13", variant=None, seed=12345):
     """states[k] = dict(x, u, cost, alpha, gap, mu, rho, iters, status, converged) of the engine under test cut at max_iters = k
-    (k = 0: the warm start).  -> list of per-step records and the end-of-solve record."""
+    (k = 0: the warm start).  For every accepted step k -> k + 1 of the engine: the oracle's ONE iteration from the engine's
+    iterate k, and the same from SENS_DRAWS copies of that iterate perturbed by PROBE_REL -- the oracle's own sensitivity at that
+    step, which is what the engine's deviation is measured against.  -> list of per-step records."""
     a0 = opts.get("alpha_0", 1.0)
     so = opts.get("second_order", 1)
+    rng = np.random.default_rng(seed)
+    o1 = oddp.DdpOptions(**dict(opts, max_iters=1))
     out = []
-    K = len(states) - 1
-    for k in range(K):
+    for k in range(len(states) - 1):
         s, t = states[k], states[k + 1]
         if t["iters"] != k + 1:                # the engine stopped before an accepted step k + 1
             break
         resume = dict(rho=s["rho"], theta=1.0 if (k > 0 and so and s["alpha"] == a0) else 0.0, closed=(k > 0 and s["gap"] == 0.0),
                       mu=s["mu"])
-        o1 = oddp.DdpOptions(**dict(opts, max_iters=1))
-        xo, uo, st, tr = cport.solve_trace(cst, o1, x0, P, s["x"], s["u"], model=model, variant=variant, resume=resume)
+        xo, uo, st, tr, a_o = _one_step(cst, o1, x0, P, s["x"], s["u"], resume, model, variant)
         J = max(abs(t["cost"]), 1e-300)
-        rec = dict(k=k + 1, alpha_engine=float(t["alpha"]), alpha_oracle=float(st[3]), oracle_iters=int(st[1]),
-                   rel_cost=abs(st[0] - t["cost"]) / J,
-                   linf_x=float(np.max(np.abs(xo - t["x"]))), linf_u=float(np.max(np.abs(uo - t["u"]))),
-                   scale_x=float(np.max(np.abs(t["x"]))), scale_u=float(np.max(np.abs(t["u"]))))
-        # how close to a tie the decision was: the smallest |Armijo margin| / |J| over the candidates the oracle tried
-        if tr:
-            m = np.abs(tr[-1]["margin"]) / max(abs(tr[-1]["J"]), 1e-300)
-            m = m[np.isfinite(m)]
-            rec["min_margin_rel"] = float(np.min(m)) if m.size else float("inf")
+        rec = dict(k=k + 1, alpha_engine=float(t["alpha"]), alpha_oracle=a_o, rel_cost=abs(st[0] - t["cost"]) / J,
+                   rel_x=float(np.max(np.abs(xo - t["x"])) / max(np.max(np.abs(t["x"])), 1e-300)),
+                   rel_u=float(np.max(np.abs(uo - t["u"])) / max(np.max(np.abs(t["u"])), 1e-300)))
+        # the oracle against itself, from perturbed copies of the same iterate
+        alphas, sens = {a_o}, 0.0
+
+        def perturbed():
+            xp = s["x"] * (1.0 + PROBE_REL * rng.standard_normal(s["x"].shape))
+            up = s["u"] * (1.0 + PROBE_REL * rng.standard_normal(s["u"].shape))
+            xp[0] = s["x"][0]
+            return xp, up
+        for _ in range(SENS_DRAWS):
+            _, _, sp, _, a_p = _one_step(cst, o1, x0, P, *perturbed(), resume, model, variant)
+            alphas.add(a_p)
+            if a_p == a_o:
+                sens = max(sens, abs(sp[0] - st[0]) / max(abs(st[0]), 1e-300))
+        if rec["alpha_engine"] != a_o:           # different step lengths from the same iterate: look harder
+            alphas.add(_one_step(cst, o1, x0, P, s["x"], s["u"], resume, model, "fast" if variant != "fast" else "off")[4])
+            for _ in range(PROBE_DRAWS):
+                alphas.add(_one_step(cst, o1, x0, P, *perturbed(), resume, model, variant)[4])
+        rec["oracle_alphas"] = sorted(alphas)
+        rec["unstable"] = len(alphas) > 1        # the oracle's own choice of step length flips under a 1e-12 perturbation
+        rec["sens"] = sens
         out.append(rec)
     return out
 
@@ -59,24 +88,31 @@ def engine_states_from_oracle(cst, opts: dict, x0, P, xs, us, model="srbd13", va
 
 
 def summarize(records):
-    """worst one-step deviations over a list of per-step records"""
+    """An instance's steps, sorted into: same step length at a stable step (deviation measured against the oracle's own
+    sensitivity), unstable steps (the oracle's own step length flips under a PROBE_REL perturbation: nothing to compare), and
+    step-length mismatches (explained iff the step is an unstable one)."""
     if not records:
-        return dict(steps=0)
-    return dict(steps=len(records),
-                alpha_mismatch=[r["k"] for r in records if r["alpha_engine"] != r["alpha_oracle"] or r["oracle_iters"] != 1],
-                max_rel_cost=max(r["rel_cost"] for r in records),
-                max_rel_x=max(r["linf_x"] / max(r["scale_x"], 1e-300) for r in records),
-                max_rel_u=max(r["linf_u"] / max(r["scale_u"], 1e-300) for r in records),
-                min_margin_rel=min(r.get("min_margin_rel", np.inf) for r in records))
+        return dict(steps=0, violations=[], alpha_mismatch=[], alpha_unexplained=[], unstable_steps=0, max_rel_cost=0.0,
+                    median_rel_cost=0.0, max_ratio=0.0)
+    stable = [r for r in records if r["alpha_engine"] == r["alpha_oracle"] and not r["unstable"]]
+    mis = [r for r in records if r["alpha_engine"] != r["alpha_oracle"]]
+    viol = [dict(k=r["k"], rel_cost=r["rel_cost"], sens=r["sens"]) for r in stable
+            if r["rel_cost"] > max(ONE_STEP_FLOOR, SENS_FACTOR * r["sens"])]
+    # explained: the oracle's own choice is not unanimous there (seen: one iterate from which 20 perturbed repeats of the oracle
+    # take step lengths from 2^-20 to 2^-5 and the engine 2^-2 -- and the second CPU build 2^-2 as well, one step later)
+    unexplained = [r["k"] for r in mis if not r["unstable"]]
+    return dict(steps=len(records), violations=viol,
+                alpha_mismatch=[dict(k=r["k"], engine=r["alpha_engine"], oracle=r["alpha_oracle"], oracle_perturbed=r["oracle_alphas"])
+                                for r in mis],
+                alpha_unexplained=unexplained, unstable_steps=sum(r["unstable"] for r in records),
+                max_rel_cost=max([r["rel_cost"] for r in stable] or [0.0]),
+                median_rel_cost=float(np.median([r["rel_cost"] for r in records])),
+                max_ratio=max([r["rel_cost"] / max(r["sens"], 1e-16) for r in stable if r["rel_cost"] > ONE_STEP_FLOOR] or [0.0]))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # whole batches: GPU engine vs C oracle, with every instance on another path explained step by step
 # ---------------------------------------------------------------------------------------------------------------------------------
-ONE_STEP_COST_RTOL = 1e-3      # worst single step (the two CPU builds of the oracle reach 1e-5 against each other on such steps)
-ONE_STEP_MEDIAN_RTOL = 1e-7    # median step of an instance
-
-
 def engine_states(model, N, opts, consts, x0, P, xs, us, kmax):
     """states[b][k] of the HIP engine for the D instances given, cut at max_iters = 0..kmax (D instances per launch)."""
     from srbd_horizon_amd.engine import DdpEngine
@@ -133,7 +169,7 @@ def explain_divergent(model, N, opts, engine_over, consts, cst, batch, idx):
         end = gs[j][kmax]
         rec = dict(instance=int(b), gpu_iters=end["iters"], oracle_iters=int(so[1]), oracle_fast_iters=int(sf[1]),
                    gpu_status=end["status"], oracle_status=int(so[6]),
-                   shadow=summarize(steps), median_rel_cost=float(np.median([r["rel_cost"] for r in steps])) if steps else 0.0,
+                   shadow=summarize(steps),
                    split_gpu=first_split(gs[j], tr_off), split_cpu_fast=first_split(tr_fast, tr_off),
                    end_linf=float(max(np.max(np.abs(end["x"] - xo)), np.max(np.abs(end["u"] - uo)))),
                    end_rel_cost=float(abs(end["cost"] - so[0]) / max(abs(so[0]), 1e-300)))
@@ -142,13 +178,14 @@ def explain_divergent(model, N, opts, engine_over, consts, cst, batch, idx):
 
 
 def assert_shadowed(rec):
-    """Every accepted step of the GPU path is the oracle's step from the same iterate."""
+    """Every accepted step of the GPU path is the oracle's step from the same iterate, as far as the oracle itself is
+    determined there."""
     s = rec["shadow"]
     assert s["steps"] == rec["gpu_iters"], rec
-    # a step length may differ only on a genuine tie of the Armijo test (margin at rounding level); none has been seen
-    assert not s["alpha_mismatch"] or s["min_margin_rel"] <= 1e-9, rec
-    assert s["max_rel_cost"] <= ONE_STEP_COST_RTOL, rec
-    assert rec["median_rel_cost"] <= ONE_STEP_MEDIAN_RTOL, rec
+    assert s["violations"] == [], rec              # stable step, same step length: cost within 10 x the oracle's own sensitivity
+    assert s["alpha_unexplained"] == [], rec       # another step length only where the oracle's own choice flips
+    assert len(s["alpha_mismatch"]) <= 3 and s["unstable_steps"] <= max(5, s["steps"] // 4), rec
+    assert s["median_rel_cost"] <= ONE_STEP_MEDIAN_RTOL, rec
 
 
 def check_batch(model, N, batch, opts, engine_over, cst, threads=16):
@@ -183,6 +220,7 @@ def parity_record(res):
                 instances=[dict(i=r["instance"], it=(r["gpu_iters"], r["oracle_iters"], r["oracle_fast_iters"]),
                                 split=(r["split_gpu"] or {}).get("step"), drift=(r["split_gpu"] or {}).get("drift_before"),
                                 cpu_split=(r["split_cpu_fast"] or {}).get("step"), cpu_drift=(r["split_cpu_fast"] or {}).get("drift_before"),
-                                step_max=r["shadow"].get("max_rel_cost"), step_med=r["median_rel_cost"],
-                                amis=len(r["shadow"].get("alpha_mismatch", [])), end_linf=r["end_linf"],
+                                step_max=r["shadow"]["max_rel_cost"], step_med=r["shadow"]["median_rel_cost"],
+                                ratio=r["shadow"]["max_ratio"], unstable=r["shadow"]["unstable_steps"],
+                                amis=r["shadow"]["alpha_mismatch"], end_linf=r["end_linf"],
                                 status=(r["gpu_status"], r["oracle_status"])) for r in ex])

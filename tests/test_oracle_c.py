@@ -136,7 +136,7 @@ def test_two_cpu_builds_of_the_oracle_shadow_each_other_step_by_step():
     (tests/test_gpu_divergence.py reports both counts).  What does hold, and is the parity statement the GPU tests make for such
     instances: every accepted step of one build is the other build's step from the same iterate (tests/shadow.py)."""
     from tests import shadow
-    N, seeds = 30, [1897, 5393]
+    N, seeds = 30, [1897, 5393, 59571]       # 59571: a step on which the two builds pick 2^-10 and 2^-1 from the same iterate
     opts = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
     batch = workload.make_batch("srbd13", N, seeds)
     cst = omodels.RobotConsts(**batch["consts"])
@@ -146,15 +146,15 @@ def test_two_cpu_builds_of_the_oracle_shadow_each_other_step_by_step():
         states = shadow.engine_states_from_oracle(cst, opts, *a, variant="fast")           # the "engine under test": build 2
         steps = shadow.shadow_one_instance(cst, opts, a[0], a[1], states)                  # checked by build 1, one step at a time
         s = shadow.summarize(steps)
-        assert s["steps"] == states[-1]["iters"] >= 50                                     # a long crawl, every step checked
-        assert s["alpha_mismatch"] == [], s
-        assert s["max_rel_cost"] <= shadow.ONE_STEP_COST_RTOL and np.median([r["rel_cost"] for r in steps]) <= shadow.ONE_STEP_MEDIAN_RTOL, s
+        assert s["steps"] == states[-1]["iters"] >= 30                                     # a long crawl, every step checked
+        shadow.assert_shadowed(dict(shadow=s, gpu_iters=states[-1]["iters"]))
         # end to end the two builds part ways (same steps until the drift is visible): reported, not asserted -- which
         # multiply-adds gcc fuses depends on the host CPU the library is built for
         _, _, _, t0 = cport.solve_trace(cst, o, *a)
         _, _, _, t1 = cport.solve_trace(cst, o, *a, variant="fast")
         print(f"seed {seeds[b]}: iterations off {sum(r['alpha'] > 0 for r in t0)} / fast {sum(r['alpha'] > 0 for r in t1)}, first split "
-              f"{shadow.first_split(t1, t0)}; worst single step {s['max_rel_cost']:.1e}")
+              f"{shadow.first_split(t1, t0)}; worst stable step {s['max_rel_cost']:.1e} = {s['max_ratio']:.1f} x the oracle's own sensitivity; "
+              f"{s['unstable_steps']} unstable steps")
 
 
 def test_resumed_oracle_solve_continues_the_same_path():
