@@ -14,6 +14,7 @@ any DDP code: the stand-in for north_star's "CasADi solve" (casadi / pyddp are a
 
 Run in the build container (sympy + scipy; minutes):   python oracle/gen_nlp_golden.py
 """
+import json
 import os
 import sys
 import time
@@ -180,9 +181,9 @@ def main(which=None):
             r = solve(name, N, batch["x0"][j], batch["params"][j], batch["xs"][j], batch["us"][j])
             path = os.path.join(OUT, f"nlp_{name}_n{N}_seed{seed}.npz")
             np.savez_compressed(path, model=name, N=N, seed=seed, x0=batch["x0"][j], params=batch["params"][j], xs0=batch["xs"][j],
-                                us0=batch["us"][j], consts_keys=np.array(sorted(batch["consts"])),
-                                consts_vals=np.array([np.asarray(batch["consts"][k], float).reshape(-1) for k in sorted(batch["consts"])],
-                                                     dtype=object), **r)
+                                us0=batch["us"][j],
+                                consts_json=np.array(json.dumps({k: np.asarray(v, float).reshape(-1).tolist()
+                                                                 for k, v in batch["consts"].items()}, sort_keys=True)), **r)
             print(f"  -> {path}: cost {r['cost']:.12e}, KKT stationarity {r['kkt_stationarity_rel']:.1e}, feasibility {r['kkt_feasibility']:.1e}")
 
 

@@ -1,0 +1,23 @@
+"""The HIP engine against the oracle-independent NLP fixtures (tests/nlp_fixtures.py): the converged solve from the fixture's own
+start must be the KKT point found WITHOUT any DDP code -- l-inf(x, u) <= 1e-4 (north_star), cost to 1e-6 relative.  This pins the
+converged result to something that shares neither the hand-written derivatives nor the Riccati sweep with the kernels."""
+import numpy as np
+import pytest
+
+from srbd_horizon_amd.engine import DdpEngine
+from tests import nlp_fixtures as nf
+
+pytestmark = pytest.mark.gpu
+FIXTURES = nf.load_all()
+
+
+@pytest.mark.parametrize("second_order", [1, 0])
+@pytest.mark.parametrize("fx", FIXTURES, ids=[f["name"] for f in FIXTURES])
+def test_hip_solve_lands_on_the_nlp_optimum(fx, second_order):
+    eng = DdpEngine(fx["model"], fx["N"], 1, opts=dict(nf.OPTS, second_order=second_order), consts=fx["consts"])
+    eng.set_initial_state(fx["x0"][None]); eng.set_x_warmstart(fx["xs0"][None]); eng.set_u_warmstart(fx["us0"][None])
+    x, u = eng.solve(fx["params"][None])
+    st = eng.stats
+    assert st["converged"][0] == 1 and st["status"][0] == 0
+    ex, eu, rc = nf.check(fx, x[0], u[0], float(st["cost"][0]))
+    print(f"{fx['name']} second_order={second_order}: {int(st['iters'][0])} iterations, linf x {ex:.1e} u {eu:.1e}, cost rel {rc:.1e}")
