@@ -68,6 +68,27 @@ def pmc_traffic(steps, depth):
         return None, None
 
 
+def pmc_issue():
+    """What binds the dominant kernel, from the committed SQ pass of the latest round (NOT a measurement of this run): share of a
+    wave's cycles in which it issues / waits, share of a SIMD's cycles in which it issues (waves per SIMD x the wave's share), and
+    algorithmic FMAs per VALU wave-instruction (0.85 Mflop per iteration = 6.6 k wave-FMAs)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        sq, per = d["SQ_mean_per_dispatch"], d["per_instance_iteration"]
+        wave_issue = sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"]
+        return {"wave_issue_frac": wave_issue, "wave_wait_frac": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                "simd_issue_frac": min(1.0, 2 * wave_issue), "valu_per_instance_iteration": per["SQ_INSTS_VALU"],
+                "lds_per_instance_iteration": per["SQ_INSTS_LDS"], "salu_per_instance_iteration": per["SQ_INSTS_SALU"],
+                "useful_valu_frac": 0.85e6 / 2 / 64 / per["SQ_INSTS_VALU"],
+                "bound": "instruction issue (fp64 VALU), not HBM", "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def cpu_quota():
     """CPU time this process's cgroup may use, in cores (None: unlimited or unknown): a box that shares its host gets fewer cores'
     worth of time than the cores it may be scheduled on."""
@@ -169,6 +190,14 @@ def seed_block(rank, world, steps, warmup, phase, i, run=0):
     return RUNS * world * steps + rank * warmup + i
 
 
+def steps_per_launch(steps, world, launches_per_region=0, queue_depth=64):
+    """Batches one launch covers.  One GPU: the whole region in one launch (the queue drains once).  N > 1 ranks: the region is
+    split over two launches by default, so that the all-gather of launch k is on the wire while launch k + 1 solves -- with one
+    launch per region the gather would be waited for with nothing to hide behind (VERDICT r04 #9)."""
+    lpr = launches_per_region if launches_per_region > 0 else (2 if world > 1 else 1)
+    return max(1, min(queue_depth, -(-steps // lpr)))
+
+
 def drain_profile(slot_t):
     """From the per-slot clocks of ONE launch ([grid, 2]: first start, queue found empty): the share of the launch during which
     fewer than half of its slots still held an instance, and the share of slot-time spent idle behind the slowest slot."""
@@ -197,6 +226,11 @@ def main():
     ap.add_argument("--waves-per-simd", type=int, default=2, help="kernel build: 1 = one wavefront per SIMD, 2 = two")
     ap.add_argument("--queue-order", type=int, default=2, help="sddp_options.queue_order: 2 largest initial cost first (no history), "
                                                               "0 index order, 1 longest previous solve first (needs history)")
+    ap.add_argument("--launches-per-region", type=int, default=0,
+                    help="split a timed region's steps over this many launches (0 = default: 1 on one GPU, 2 with N > 1 ranks, so that "
+                         "the all-gather of launch k is on the wire while launch k + 1 solves)")
+    ap.add_argument("--gather", default="full", choices=("full", "first_knot"),
+                    help="what the N > 1 all-gather carries per instance: the whole plan (SURVEY 8(e), 4 680 B) or u_0 | x_1 | cost | iterations (168 B)")
     ap.add_argument("--no-extras", action="store_true", help="skip the index-order, replay and one-batch-in-flight measurements")
     args = ap.parse_args()
 
@@ -232,7 +266,7 @@ def main():
 
     N, B = args.horizon, args.batch
     steps, warmup = max(args.steps, 1), max(args.warmup, 0)
-    Q = max(1, min(args.queue_depth, steps))
+    Q = steps_per_launch(steps, world, args.launches_per_region, args.queue_depth)
     nx, nu, npar = 13, 6, 19
     opts = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsrbd_example.py:55-58
     wps = args.waves_per_simd
@@ -250,12 +284,12 @@ def main():
     d_t = d_runs[0]
     d_w = load_blocks(warm_blocks) if warmup else None
 
-    def make_queue(order, **over):
-        e = DdpEngine("srbd13", N, Q * B, opts=dict(opts, waves_per_simd=wps, queue_order=order, **over))
+    def make_queue(order, depth=None, **over):
+        e = DdpEngine("srbd13", N, (depth or Q) * B, opts=dict(opts, waves_per_simd=wps, queue_order=order, **over))
         e.use_torch_stream(torch.cuda.current_stream())
         e.enable_timing(True)
-        P_all = torch.zeros((Q * B, N + 1, npar), dtype=torch.float64, device=dev)      # the handle's parameter tensor, resident
-        return e, FleetQueue(e, P_all, B, Q, collective=collective)
+        P_all = torch.zeros(((depth or Q) * B, N + 1, npar), dtype=torch.float64, device=dev)      # the handle's parameter tensor, resident
+        return e, FleetQueue(e, P_all, B, depth or Q, collective=collective, gather=args.gather)
 
     eng, fleet = make_queue(args.queue_order)
     acc = torch.zeros(2, dtype=torch.int64, device=dev)        # DDP iterations, rollouts over all launches (device-side sums)
@@ -353,7 +387,9 @@ def main():
                    "waves_per_simd": wps, "queue_order": ORDER_NAMES[args.queue_order], "streams": 1,
                    "seed_blocks": {"timed": [timed_blocks[0], timed_blocks[-1]], "warmup": ([warm_blocks[0], warm_blocks[-1]] if warmup else None),
                                    "block": f"seeds b*{B} .. b*{B}+{B - 1}"},
-                   "collective": "asynchronous double-buffered all_gather(solution records) per launch, waited for inside the timed region"
+                   "launches_per_region": -(-steps // Q),
+                   "collective": (f"asynchronous double-buffered all_gather of the '{args.gather}' record per launch (packed by one HIP kernel behind "
+                                  "the solve); the gather of launch k is on the wire while launch k + 1 solves; all waited for inside the timed region")
                                  if collective else "none",
                    "gather_bytes_per_launch_per_rank": (med["gbytes"] // max(launches, 1)) if collective else 0,
                    "seed_blocks_of_the_runs": [r["blocks"] for r in regions]},
@@ -364,10 +400,11 @@ def main():
         "iterations_per_s": world * tot_iters / elapsed,
         # secondary: ~0.85 Mflop of fp64 per DDP iteration at (N, nx, nu) = (30, 13, 6) (dense backward
         # sweep 25.2 kflop/knot + model evaluation + one rollout), against the MI355X fp64 vector peak of 78.6 TFLOP/s
-        "fp64_algorithmic_tflops": world * tot_iters / elapsed * 0.85e6 * (N / 30.0) / 1e12,
-        "fp64_vector_peak_frac": tot_iters / elapsed * 0.85e6 * (N / 30.0) / 78.6e12,
+        # (DENSE-EQUIVALENT flops: the sweep that runs skips the zeros of [fx fu] and does fewer)
+        "fp64_dense_equivalent_tflops": world * tot_iters / elapsed * 0.85e6 * (N / 30.0) / 1e12,
+        "fp64_dense_equivalent_vector_peak_frac": tot_iters / elapsed * 0.85e6 * (N / 30.0) / 78.6e12,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic": traffic, "traffic_source": traffic_src, "issue": pmc_issue(),
                      "kernel": eng.kernel_info()["kernel"], "resources": eng.kernel_info().get("resources"), "kernel_ms": kms,
                      "launches": int(kcnt), "algorithmic_bytes_per_launch": abytes_launch,
                      "note": "achieved = algorithmic bytes of the average timed launch (SURVEY 8(d) bytes per solve, from the iteration "
@@ -418,7 +455,15 @@ def main():
             el1 += time.perf_counter() - t1
         out["one_batch_in_flight_solves_per_s"] = B * n1 / el1
         out["one_batch_in_flight_ms_per_step"] = 1e3 * el1 / n1
+        out["roofline"]["one_batch_in_flight_solves_per_s"] = out["one_batch_in_flight_solves_per_s"]
         del f_lat, e_lat
+        # what the N > 1 default costs on ONE GPU: the same region as two launches of steps / 2 batches (the shape in which the
+        # all-gather of launch k hides behind launch k + 1): each launch drains on its own
+        if Q >= steps and steps >= 2:
+            e_o, f_o = make_queue(args.queue_order, depth=-(-steps // 2))
+            run_steps(f_o, d_w if warmup else d_t, min(max(warmup, 1), -(-steps // 2)))
+            out["two_launches_per_region_solves_per_s"] = B * steps / timed(f_o, d_t, steps)
+            del f_o, e_o
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # The tick loops below report a p99 / max per tick.  CPython's generation-2 garbage collection walks every tracked object
         # of the process (31 ms with torch imported) once per ~70 k container allocations: the "one-time 20-45 ms stall" of rounds
@@ -442,6 +487,7 @@ def main():
             e_h.solve(batch["params"])
             t_host.append(time.perf_counter() - t1)
         out["pcie_inclusive_solves_per_s"] = B / min(t_host)
+        out["roofline"]["pcie_inclusive_solves_per_s"] = out["pcie_inclusive_solves_per_s"]
         out["cpu_baseline"] = cpu_baseline(N, B, timed_blocks[:2])
     if collective and world == 1:
         out["collective_rehearsal"] = True
@@ -484,8 +530,8 @@ def mw_batch(model, N, B, opts, workload, DdpEngine, reps=3):
             "max_iters": int(iters.max()), "mean_rollouts": float(np.mean(roll)), "converged_frac": float(np.mean(st["converged"] == 1)),
             "slots": slots, "grid": grid, "kernel": e.kernel_info()["kernel"], "resources": e.kernel_info().get("resources"), "kernel_ms": kms,
             "algorithmic_bytes": ab, "achieved_gbs": ab / (kms * 1e-3) / 1e9, "hbm_frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "fp64_algorithmic_tflops": float(iters.sum()) * flop_it / (kms * 1e-3) / 1e12,
-            "fp64_vector_peak_frac": float(iters.sum()) * flop_it / (kms * 1e-3) / 78.6e12,
+            "fp64_dense_equivalent_tflops": float(iters.sum()) * flop_it / (kms * 1e-3) / 1e12,
+            "fp64_dense_equivalent_vector_peak_frac": float(iters.sum()) * flop_it / (kms * 1e-3) / 78.6e12,
             "note": f"{model} N={N} cold start, one launch of {B} instances (queue on {grid} slots of 4 wavefronts, largest initial cost "
                     "first); solves_per_s includes the host-pointer result fetch, kernel_* is the HIP-event kernel time"}
 

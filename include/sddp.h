@@ -173,6 +173,13 @@ int  sddp_synchronize(sddp_handle* h);
  * of an instance is bit-identical whatever range, order or slot it runs in. */
 int  sddp_load_range_device(sddp_handle* h, int first, int count, const double* d_x0, const double* d_x, const double* d_u);
 int  sddp_solve_range_device(sddp_handle* h, const double* d_params, int first, int count);
+/* The solution record an instance-sharded fleet exchanges after a launch (one all-gather per launch):
+ * the instances [first, first + count) packed [count][words] into d_out (a DEVICE pointer, e.g. the collective's send buffer) by
+ * one kernel behind the solve on the handle's stream.  mode 0: x [N+1][nx] | u [N][nu] | cost | iterations (the whole plan);
+ * mode 1: u_0 [nu] | x_1 [nx] | cost | iterations (what a closed loop applies next; 168 B instead of 4 680 B at (30, 13, 6)).
+ * sddp_record_words: doubles per record.  (v9) */
+int  sddp_record_words(sddp_handle* h, int mode, int* words);
+int  sddp_pack_records_device(sddp_handle* h, int first, int count, int mode, double* d_out);
 /* slots: resident workgroups the work buffers exist for; grid and queue length (0: no queue) of the last solve launch */
 int  sddp_queue_info(sddp_handle* h, int* slots, int* last_grid, int* last_queued);
 /* which kernel a handle runs: wavefronts per instance (1: solve_kernel, 4: solve_kernel_mw), the build the LAST solve launch used

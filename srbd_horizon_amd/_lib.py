@@ -86,6 +86,8 @@ SYMBOLS = {
     "sddp_solve_device": (C.c_int, [_vp, _vp]),
     "sddp_load_range_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "sddp_solve_range_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "sddp_record_words": (C.c_int, [_vp, C.c_int, _P(C.c_int)]),
+    "sddp_pack_records_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "sddp_queue_info": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "sddp_fetch": (C.c_int, [_vp, _vp, _vp, _vp]),
     "sddp_synchronize": (C.c_int, [_vp]),

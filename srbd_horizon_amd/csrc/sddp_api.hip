@@ -625,6 +625,26 @@ int sddp_solve_resident_first(sddp_handle* h, double* u0_out, double* x1_out, do
     return SDDP_OK;
 }
 
+int sddp_record_words(sddp_handle* h, int mode, int* words) {
+    if (!h || !words) return SDDP_ERR_ARG;
+    if (mode != 0 && mode != 1) return fail(h, SDDP_ERR_ARG, "record mode must be 0 (whole plan) or 1 (first knot)");
+    *words = mode == 0 ? (h->N + 1) * h->d.nx + h->N * h->d.nu + 2 : h->d.nu + h->d.nx + 2;
+    return SDDP_OK;
+}
+
+int sddp_pack_records_device(sddp_handle* h, int first, int count, int mode, double* d_out) {
+    if (!h || !d_out) return SDDP_ERR_ARG;
+    if (mode != 0 && mode != 1) return fail(h, SDDP_ERR_ARG, "record mode must be 0 (whole plan) or 1 (first knot)");
+    if (first < 0 || count < 1 || first > h->B - count) return fail(h, SDDP_ERR_ARG, "instance range outside the batch");
+    int w = 0;
+    sddp_record_words(h, mode, &w);
+    const int grid = int(std::min<size_t>((size_t(count) * w + 255) / 256, 2048));
+    hipLaunchKernelGGL(pack_records_kernel, dim3(grid), dim3(256), 0, h->stream, h->N, h->d.nx, h->d.nu, first, count, mode, h->xs, h->us,
+                       h->stats, d_out);
+    HIP_TRY(h, hipGetLastError());
+    return SDDP_OK;
+}
+
 int sddp_model_step(sddp_handle* h, const double* x, const double* u, const double* p, int k, double* x_next) {
     if (!h || !x || !u || !p || !x_next) return SDDP_ERR_ARG;
     if (k < 0 || k >= h->N) return fail(h, SDDP_ERR_ARG, "sddp_model_step: k must be a stage node, 0 <= k < N");

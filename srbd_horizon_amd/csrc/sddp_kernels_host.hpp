@@ -50,6 +50,32 @@ __global__ __launch_bounds__(256) void first_knot_kernel(int N, int B, int nx, i
     }
 }
 
+// The record an instance-sharded fleet exchanges after a launch: per instance
+//   mode 0: x [N+1][nx] | u [N][nu] | cost | iterations            ((N+1) nx + N nu + 2 doubles: the whole plan)
+//   mode 1: u_0 [nu] | x_1 [nx] | cost | iterations                (nu + nx + 2 doubles: what a closed loop applies next)
+// written [count][words] contiguous into the collective's send buffer: one kernel, whole-wave contiguous stores (the trajectories
+// of consecutive instances are consecutive in xs / us, so the loads are contiguous runs too).
+__global__ __launch_bounds__(256) void pack_records_kernel(int N, int nx, int nu, int first, int count, int mode,
+                                                           const double* __restrict__ xs, const double* __restrict__ us,
+                                                           const sddp_stats* __restrict__ st, double* __restrict__ out) {
+    const int nxw = mode == 0 ? (N + 1) * nx : nx, nuw = mode == 0 ? N * nu : nu;
+    const int w = nxw + nuw + 2;
+    for (size_t e = size_t(blockIdx.x) * 256 + threadIdx.x; e < size_t(count) * w; e += size_t(gridDim.x) * 256) {
+        const int i = int(e / w), j = int(e % w), b = first + i;
+        double v;
+        if (mode == 0) {
+            if (j < nxw) v = xs[size_t(b) * nxw + j];
+            else if (j < nxw + nuw) v = us[size_t(b) * nuw + (j - nxw)];
+            else v = j == nxw + nuw ? st[b].cost : double(st[b].iters);
+        } else {
+            if (j < nu) v = us[size_t(b) * N * nu + j];
+            else if (j < nu + nx) v = xs[(size_t(b) * (N + 1) + 1) * nx + (j - nu)];
+            else v = j == nu + nx ? st[b].cost : double(st[b].iters);
+        }
+        out[e] = v;
+    }
+}
+
 // diagnostic (sddp_debug_poison_lds): a workgroup that owns a CU's whole LDS and fills it with NaNs.  What a kernel finds in LDS
 // is whatever the previous one left there; after this one a read of a word the kernel never wrote cannot pass a parity test.
 __global__ __launch_bounds__(256) void poison_lds_kernel(int words, int* __restrict__ sink) {

@@ -17,8 +17,9 @@ def shard_range(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def record_words(N: int, nx: int, nu: int) -> int:
-    return (N + 1) * nx + N * nu + 2
+def record_words(N: int, nx: int, nu: int, mode: str = "full") -> int:
+    """doubles per instance record: "full" x | u | cost | iterations; "first_knot" u_0 | x_1 | cost | iterations"""
+    return (N + 1) * nx + N * nu + 2 if mode == "full" else nu + nx + 2
 
 
 def pack_records(x, u, cost, iters):
@@ -33,9 +34,17 @@ def pack_records(x, u, cost, iters):
                       iters.reshape(B, 1).to(torch.float64)], dim=1).contiguous()
 
 
-def pack_records_into(out, x, u, cost, iters):
-    """pack_records into a preallocated [B, words] torch tensor (no allocation: the fleet queue's pack buffers); -> out"""
+def pack_records_into(out, x, u, cost, iters, mode: str = "full"):
+    """pack_records into a preallocated [B, words] torch tensor (host-side form of csrc pack_records_kernel, which the HIP engine
+    uses: engine.pack_records_device); -> out"""
     B = x.shape[0]
+    if mode == "first_knot":
+        nu, nx = u.shape[2], x.shape[2]
+        out[:, :nu].copy_(u[:, 0])
+        out[:, nu:nu + nx].copy_(x[:, 1])
+        out[:, nu + nx].copy_(cost)
+        out[:, nu + nx + 1].copy_(iters)
+        return out
     nxw, nuw = x.shape[1] * x.shape[2], u.shape[1] * u.shape[2]
     out[:, :nxw].copy_(x.reshape(B, nxw))
     out[:, nxw:nxw + nuw].copy_(u.reshape(B, nuw))

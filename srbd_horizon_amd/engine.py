@@ -232,6 +232,20 @@ class DdpEngine:
         """One asynchronous launch over the instances [first, first + count); `params` is the whole [B, N+1, np] tensor."""
         self._chk(self.lib.sddp_solve_range_device(self.h, self._dev(params, (self.B, self.N + 1, self.np_)), int(first), int(count)))
 
+    RECORD_MODES = {"full": 0, "first_knot": 1}
+
+    def record_words(self, mode="full"):
+        w = C.c_int()
+        self._chk(self.lib.sddp_record_words(self.h, self.RECORD_MODES[mode], C.byref(w)))
+        return w.value
+
+    def pack_records_device(self, out, first: int, count: int, mode="full"):
+        """The solution records of the instances [first, first + count) into the device tensor `out` [count, record_words(mode)]
+        (one kernel on the handle's stream, behind the solve): what a sharded fleet's all-gather sends."""
+        self._chk(self.lib.sddp_pack_records_device(self.h, int(first), int(count), self.RECORD_MODES[mode],
+                                                    self._dev(out, (count, self.record_words(mode)))))
+        return out
+
     def last_queue_order(self):
         """Instance indices in the order the last queued launch handed them out (queue_order 1 or 2); waits for the stream."""
         import torch

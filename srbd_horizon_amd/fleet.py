@@ -29,8 +29,14 @@ from . import dist as sdist
 
 
 class FleetQueue:
-    def __init__(self, engine, params_all, batch: int, depth: int, collective: bool = False):
+    def __init__(self, engine, params_all, batch: int, depth: int, collective: bool = False, gather: str = "full"):
+        """gather: what the closing all-gather carries per instance -- "full": x | u | cost | iterations, the whole plan
+        (4 680 B at (30, 13, 6)); "first_knot": u_0 | x_1 | cost | iterations (168 B), what a fleet in
+        closed loop needs from the other ranks."""
         self.eng, self.P, self.batch, self.depth, self.collective = engine, params_all, int(batch), int(depth), bool(collective)
+        if gather not in ("full", "first_knot"):
+            raise ValueError("gather must be 'full' or 'first_knot'")
+        self.gather = gather
         if tuple(params_all.shape[:1]) != (self.batch * self.depth,):
             raise ValueError("params_all must hold depth * batch instances")
         self.pending = 0            # batches loaded and not yet solved
@@ -50,7 +56,7 @@ class FleetQueue:
             import torch
             import torch.distributed as dist
             self.world = dist.get_world_size()
-            words = self.x.shape[1] * self.x.shape[2] + self.u.shape[1] * self.u.shape[2] + 2
+            words = sdist.record_words(self.x.shape[1] - 1, self.x.shape[2], self.u.shape[2], gather)
             cap = self.batch * self.depth
             mk = lambda rows: torch.empty((rows, words), dtype=torch.float64, device=self.x.device)
             self._pack = [mk(cap), mk(cap)]
@@ -83,7 +89,11 @@ class FleetQueue:
             import torch.distributed as dist
             k = self._k
             self._wait(k)                                                    # this pair's previous collective (two flushes ago)
-            local = sdist.pack_records_into(self._pack[k][:n], self.x[:n], self.u[:n], self.sf[:n, _lib.STATS_F64_COST], self.si[:n, _lib.STATS_I32_ITERS])
+            if hasattr(self.eng, "pack_records_device"):                   # the HIP engine: ONE kernel behind the solve
+                local = self.eng.pack_records_device(self._pack[k][:n], 0, n, self.gather)
+            else:                                                            # engine stand-in of the CPU tests
+                local = sdist.pack_records_into(self._pack[k][:n], self.x[:n], self.u[:n], self.sf[:n, _lib.STATS_F64_COST],
+                                                self.si[:n, _lib.STATS_I32_ITERS], self.gather)
             self._work[k] = dist.all_gather_into_tensor(self._out[k][:self.world * n], local, async_op=True)
             self._n[k] = n
             self.gather_bytes += local.numel() * local.element_size()

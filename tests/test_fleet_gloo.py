@@ -62,12 +62,12 @@ def _seeds(rank, steps, step, B):
     return (rank * steps + step) * B + np.arange(B)                    # bench.py: every step of every rank solves its own instances
 
 
-def _worker(rank, world, port, B, depth, steps, q):
+def _worker(rank, world, port, B, depth, steps, q, gather="full"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     P0 = torch.zeros(depth * B, N + 1, NP, dtype=torch.float64)
-    fleet = FleetQueue(OracleEngine(depth * B), P0, B, depth, collective=True)
+    fleet = FleetQueue(OracleEngine(depth * B), P0, B, depth, collective=True, gather=gather)
     out = []
     held = None                                                        # launch k's gathered view, read again after launch k + 1 started
     for s in range(steps):
@@ -92,18 +92,20 @@ def _worker(rank, world, port, B, depth, steps, q):
     dist.destroy_process_group()
 
 
-def test_fleet_step_world2_gathers_every_ranks_records():
+@pytest.mark.parametrize("gather", ["full", "first_knot"])
+def test_fleet_step_world2_gathers_every_ranks_records(gather):
     world, B, depth, steps = 2, 4, 2, 5                                # 5 steps on a depth-2 handle: launches of 2, 2 and 1 batches
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, B, depth, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, depth, steps, q, gather)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
-    W = sdist.record_words(N, NX, NU)
+    W = sdist.record_words(N, NX, NU, gather)
+    assert W == (N + 1) * NX + N * NU + 2 if gather == "full" else W == NU + NX + 2 == 21
     # unsharded reference of each launch: rank-major, each rank's block = its steps of that launch in order
     launches = [[0, 1], [2, 3], [4]]
     refs = []
@@ -125,9 +127,14 @@ def test_fleet_step_world2_gathers_every_ranks_records():
                 xo, uo, so = refs[li]
                 li += 1
             assert rec.shape == (xo.shape[0], W)
-            x, u, cost, iters = sdist.unpack_records(rec, N, NX, NU)
-            np.testing.assert_array_equal(x, xo)
-            np.testing.assert_array_equal(u, uo)
+            if gather == "full":
+                x, u, cost, iters = sdist.unpack_records(rec, N, NX, NU)
+                np.testing.assert_array_equal(x, xo)
+                np.testing.assert_array_equal(u, uo)
+            else:                                                          # u_0 | x_1 | cost | iterations
+                np.testing.assert_array_equal(rec[:, :NU], uo[:, 0])
+                np.testing.assert_array_equal(rec[:, NU:NU + NX], xo[:, 1])
+                cost, iters = rec[:, NU + NX], rec[:, NU + NX + 1]
             np.testing.assert_array_equal(cost, so[:, 0])
             np.testing.assert_array_equal(iters, so[:, 1])
     for a, b in zip(res[0][3], res[1][3]):

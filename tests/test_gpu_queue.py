@@ -148,3 +148,28 @@ def test_gains_pointer_is_refused_after_a_queued_launch():
     _solve(q, batch)
     with pytest.raises(RuntimeError, match="per queue slot"):
         q.device_buffer(3)
+
+
+@pytest.mark.parametrize("mode", ["full", "first_knot"])
+def test_pack_records_kernel_writes_the_gather_record(mode):
+    """sddp_pack_records_device (the one kernel that fills the all-gather's send buffer) against the host-side packing of
+    srbd_horizon_amd.dist on the fetched results: bit-exact, any range of the batch."""
+    from srbd_horizon_amd import dist as sdist
+    N, B = 30, 24
+    batch = workload.make_batch("srbd13", N, np.arange(B) + 77)
+    eng = _engine("srbd13", N, B)
+    x, u, st = _solve(eng, batch)
+    W = eng.record_words(mode)
+    assert W == sdist.record_words(N, 13, 6, mode)
+    dev = torch.device("cuda", 0)
+    for first, count in ((0, B), (5, 7), (B - 1, 1)):
+        out = torch.full((count, W), float("nan"), dtype=torch.float64, device=dev)
+        eng.pack_records_device(out, first, count, mode)
+        eng.synchronize()
+        ref = torch.empty((count, W), dtype=torch.float64)
+        sl = slice(first, first + count)
+        sdist.pack_records_into(ref, torch.from_numpy(x[sl]), torch.from_numpy(u[sl]), torch.from_numpy(st["cost"][sl].copy()),
+                                torch.from_numpy(st["iters"][sl].copy()), mode)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref.numpy())
+    with pytest.raises(RuntimeError):
+        eng.pack_records_device(torch.empty((2, W), dtype=torch.float64, device=dev), B - 1, 2, mode)      # range past the batch
