@@ -191,10 +191,12 @@ def seed_block(rank, world, steps, warmup, phase, i, run=0):
 
 
 def steps_per_launch(steps, world, launches_per_region=0, queue_depth=64):
-    """Batches one launch covers.  One GPU: the whole region in one launch (the queue drains once).  N > 1 ranks: the region is
-    split over two launches by default, so that the all-gather of launch k is on the wire while launch k + 1 solves -- with one
-    launch per region the gather would be waited for with nothing to hide behind (VERDICT r04 #9)."""
-    lpr = launches_per_region if launches_per_region > 0 else (2 if world > 1 else 1)
+    """Batches one launch covers.  Default: the whole region in ONE launch, for any number of ranks.  Splitting a region so that
+    the all-gather of launch k hides behind launch k + 1 (--launches-per-region 2) was measured on one GPU with a one-rank RCCL
+    communicator: 310 k solves/s against 420 k -- every launch drains on its own, and two half-length queues idle far more slot
+    time (26 %) than the gather they hide could cost (47.9 MB per rank and launch: 1-2 ms of a 48 ms launch).  The option
+    stays for nodes where the gather turns out slower than that."""
+    lpr = launches_per_region if launches_per_region > 0 else 1
     return max(1, min(queue_depth, -(-steps // lpr)))
 
 
@@ -227,8 +229,8 @@ def main():
     ap.add_argument("--queue-order", type=int, default=2, help="sddp_options.queue_order: 2 largest initial cost first (no history), "
                                                               "0 index order, 1 longest previous solve first (needs history)")
     ap.add_argument("--launches-per-region", type=int, default=0,
-                    help="split a timed region's steps over this many launches (0 = default: 1 on one GPU, 2 with N > 1 ranks, so that "
-                         "the all-gather of launch k is on the wire while launch k + 1 solves)")
+                    help="split a timed region's steps over this many launches (0 = default = 1; 2: the all-gather of launch k is on "
+                         "the wire while launch k + 1 solves, at the price of two drains)")
     ap.add_argument("--gather", default="full", choices=("full", "first_knot"),
                     help="what the N > 1 all-gather carries per instance: the whole plan (SURVEY 8(e), 4 680 B) or u_0 | x_1 | cost | iterations (168 B)")
     ap.add_argument("--no-extras", action="store_true", help="skip the index-order, replay and one-batch-in-flight measurements")

@@ -28,13 +28,6 @@ constexpr int kWave = 64;
 #define SDDP_KSLOTS 6
 #endif
 constexpr int kSlots = SDDP_KSLOTS;   // line-search candidates whose trajectories are kept per pass (one-wave kernel)
-// A solve that is still running after this many accepted iterations is one of the few long ones a launch ends with (mean 16, the
-// longest 100): its wavefronts then issue at raised priority (s_setprio), ahead of the SIMD partner's -- the launch's critical
-// path shortens at the expense of instances that have slack.  No effect on results.  0 = off.
-#ifndef SDDP_PRIO_AFTER
-#define SDDP_PRIO_AFTER 0
-#endif
-constexpr int kPrioAfter = SDDP_PRIO_AFTER;
 constexpr int kScal = 24;  // doubles per instance in the scratch `scal` record (test kernels / diagnostic stamps)
 
 // Diagnostic build only (-DSDDP_STAMPS): per-phase shader-cycle sums, written to `scal`; never in the shipped library.
@@ -905,12 +898,10 @@ __device__ __forceinline__ void solve_instance(const SolveArgs& A, double* s, co
             }
             gap *= oma;
             ++iters;
-            if (kPrioAfter > 0 && iters == kPrioAfter) __builtin_amdgcn_s_setprio(3);
             if (mu > o.mu0) mu = fmax(o.mu0, mu * 0.1);
             wave_sync();
             if (fabs(dJ) < o.cost_reduction_ths && gap <= o.gap_tol) { converged = 1; status = 0; break; }
         }
-    if (kPrioAfter > 0) __builtin_amdgcn_s_setprio(0);
     // ---- results live in A.xs/A.us: copy back if the iterate ended in the candidate buffers
     wave_sync();
     double* xs0 = A.xs + size_t(b) * (N + 1) * NX;

@@ -84,8 +84,10 @@ def test_queue_model_reproduces_the_design_table():
     assert m["index", 4] > m["index", 1] and m["exact", 4] > 1.5 * m["exact", 1]
 
 
-def test_more_than_one_rank_splits_a_region_over_two_launches():
-    """N > 1: the gather of launch k must have a launch k + 1 to hide behind (bench.steps_per_launch)."""
-    assert bench.steps_per_launch(20, 1) == 20 and bench.steps_per_launch(20, 8) == 10 and bench.steps_per_launch(5, 2) == 3
+def test_steps_per_launch():
+    """one launch per region by default at any world size (two drains cost more than the gather they would hide: measured);
+    --launches-per-region splits it (bench.steps_per_launch)."""
+    assert bench.steps_per_launch(20, 1) == 20 and bench.steps_per_launch(20, 8) == 20
+    assert bench.steps_per_launch(20, 8, launches_per_region=2) == 10 and bench.steps_per_launch(5, 2, launches_per_region=2) == 3
     assert bench.steps_per_launch(20, 8, launches_per_region=4) == 5 and bench.steps_per_launch(96, 1, queue_depth=64) == 64
-    assert bench.steps_per_launch(1, 8) == 1
+    assert bench.steps_per_launch(1, 8, launches_per_region=2) == 1
