@@ -107,6 +107,10 @@ typedef struct sddp_model_consts {
     double bound_barrier_sharpness;    /* 6 */
     double lower[64];
     double upper[64];
+    /* prb.py:166-170 adds the relative-velocity constraints cdot_lead,xy - cdot_i,xy inside a foot only `if contact_model > 1`.
+     * 1 (default): they are there -- contact_model = 2 (srbd37, lip30) or 4 (srbd61).  0: the same state layout with POINT feet,
+     * number_of_legs = 4 x contact_model = 1 (nc = 4 on the srbd37 / lip30 build): no such rows.  (v9) */
+    int    relative_velocity_constraints;
 } sddp_model_consts;
 
 /* per-instance solve record (what pyddp exposes only as is_converged(), ddp.py:106, plus the tic/toc of

@@ -21,11 +21,12 @@ typedef struct {
     double w_rel, w_zmp, lip_h, feet[12];
     int inertia_mode;
     double box_w, box_s, lower[64], upper[64];   /* bound barrier (oracle/models.py _bound_rows, ddp.py:203-208): off when box_w == 0 */
+    int rv;                        /* relative-velocity constraints inside a foot present (prb.py:166: `if contact_model > 1`) */
 } consts_t;
 
 /* packed constants from Python: m, I[9], com_z, dt, force_scaling, r_gain, rdot_gain, w_gain, fsw, qddot, minf, inertia_mode, lever,
  * friction_cone_coefficient, friction_barrier_weight, friction_barrier_sharpness, rel_pos_gain, zmp_gain, lip_height, feet[12],
- * bound_barrier_weight, bound_barrier_sharpness, lower[64], upper[64] */
+ * bound_barrier_weight, bound_barrier_sharpness, lower[64], upper[64], relative_velocity_constraints */
 static void unpack_consts(const double* c, consts_t* k) {
     const double m = c[0], fs = c[12];
     k->inv_ms = fs / m;
@@ -39,6 +40,7 @@ static void unpack_consts(const double* c, consts_t* k) {
     for (int i = 0; i < 12; ++i) k->feet[i] = c[27 + i];
     k->box_w = c[39]; k->box_s = c[40];
     for (int i = 0; i < 64; ++i) { k->lower[i] = c[41 + i]; k->upper[i] = c[105 + i]; }
+    k->rv = c[169] != 0.0;
 }
 
 static void cross(const double* a, const double* b, double* o) {
@@ -351,15 +353,15 @@ static int rel_pos_rows(const consts_t* c, const double* x, const int* C0, doubl
  * cm = nc / 2 per foot: relative_vel_left_i (cdot_0 - cdot_i, i = 1..cm-1), relative_vel_right_i (cdot_cm - cdot_i, i = cm+1..2cm-1),
  * then per contact cz_tracking_i and cdotxy_tracking_i: 4 (cm - 1) + 3 nc rows */
 static int contact_penalty_rows(const double* x, int nc, const int* C0, const int* CD0, const double* cref, const double* sw, double* r,
-                                double* J, int nz, int n) {
-    const double g = sqrt(CW);
+                                double* J, int nz, int n, int rv) {
+    const double g = sqrt(CW), grv = rv ? g : 0.0;     /* rv == 0 (contact_model = 1): the rows stay, as zeros */
     const int cm = nc / 2;
     for (int leg = 0; leg < 2; ++leg)
         for (int i = 1; i < cm; ++i) {
             const int lead = leg * cm, foll = leg * cm + i;
             for (int e = 0; e < 2; ++e) {
-                r[n + e] = g * (x[CD0[lead] + e] - x[CD0[foll] + e]);
-                if (J) { J[(n + e) * nz + CD0[lead] + e] = g; J[(n + e) * nz + CD0[foll] + e] = -g; }
+                r[n + e] = grv * (x[CD0[lead] + e] - x[CD0[foll] + e]);
+                if (J) { J[(n + e) * nz + CD0[lead] + e] = grv; J[(n + e) * nz + CD0[foll] + e] = -grv; }
             }
             n += 2;
         }
@@ -555,7 +557,7 @@ static int l30_residual(const consts_t* c, const double* x, const double* u, con
         n += 15;
         double cref[4], sw[4];
         for (int i = 0; i < 4; ++i) { cref[i] = p[3 + 2 * i]; sw[i] = p[4 + 2 * i]; }
-        n = contact_penalty_rows(x, 4, L30_C, L30_CD, cref, sw, r, J, nz, n);
+        n = contact_penalty_rows(x, 4, L30_C, L30_CD, cref, sw, r, J, nz, n, c->rv);
     }
     return n;
 }

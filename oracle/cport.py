@@ -51,7 +51,8 @@ def pack_consts(cst, model=None):
                      cst.min_qddot_gain, cst.min_f_gain, float(cst.inertia_mode), cst.lever_sign,
                      cst.friction_cone_coefficient, cst.friction_barrier_weight, cst.friction_barrier_sharpness,
                      cst.rel_pos_gain, cst.zmp_tracking_gain, cst.lip_height, *feet,
-                     cst.bound_barrier_weight, cst.bound_barrier_sharpness, *_bounds64(cst.lower, -np.inf), *_bounds64(cst.upper, np.inf)],
+                     cst.bound_barrier_weight, cst.bound_barrier_sharpness, *_bounds64(cst.lower, -np.inf), *_bounds64(cst.upper, np.inf),
+                     float(bool(getattr(cst, "relative_velocity_constraints", True)))],
                     dtype=np.float64)
 
 

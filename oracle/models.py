@@ -68,6 +68,9 @@ class RobotConsts:
     bound_barrier_sharpness: float = 6.0        # exp_parameter, ddp.py:182
     lower: np.ndarray | None = None
     upper: np.ndarray | None = None
+    # prb.py:166-170: the relative-velocity constraints inside a foot exist only `if contact_model > 1`.  False = the same state
+    # layout with number_of_legs = 4 point feet (contact_model = 1, nc = 4): no such rows
+    relative_velocity_constraints: bool = True
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -676,7 +679,8 @@ class SRBD37(Model):
             for i in range(nc):
                 _force_rows(rows, c, fs[i], p[self.p_sw(i)], 6 * i + 3)
             _contact_penalty_rows(rows, cs, cds, [p[self.p_cref(i)] for i in range(nc)],
-                                  [p[self.p_sw(i)] for i in range(nc)], self.C_IDX, self.CD_IDX, self.contact_model)
+                                  [p[self.p_sw(i)] for i in range(nc)], self.C_IDX, self.CD_IDX,
+                                  self.contact_model if c.relative_velocity_constraints else 1)
             _bound_rows(rows, c, xs, u)
         return rows.stack()
 
@@ -807,7 +811,8 @@ class LIP30(Model):
             Ju[3:15, 3:15] = np.eye(12)
             rows.add(g * np.concatenate([rddot, u[3:15]]), g * Jx, g * Ju)          # min_qddot prb.py:402
             _contact_penalty_rows(rows, cs, cds, [p[self.p_cref(i)] for i in range(4)],
-                                  [p[self.p_sw(i)] for i in range(4)], self.C_IDX, self.CD_IDX, self.contact_model)
+                                  [p[self.p_sw(i)] for i in range(4)], self.C_IDX, self.CD_IDX,
+                                  self.contact_model if c.relative_velocity_constraints else 1)
         return rows.stack()
 
     def initial_state(self):

@@ -38,7 +38,7 @@ class SddpModelConsts(C.Structure):
                 ("inertia_mode", C.c_int), ("lever_sign", C.c_double), ("friction_cone_coefficient", C.c_double),
                 ("friction_barrier_weight", C.c_double), ("friction_barrier_sharpness", C.c_double),
                 ("bound_barrier_weight", C.c_double), ("bound_barrier_sharpness", C.c_double),
-                ("lower", C.c_double * 64), ("upper", C.c_double * 64)]
+                ("lower", C.c_double * 64), ("upper", C.c_double * 64), ("relative_velocity_constraints", C.c_int)]
 
 
 class SddpStats(C.Structure):

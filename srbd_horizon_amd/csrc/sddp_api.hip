@@ -197,6 +197,7 @@ int sddp_default_consts_for(int model_id, sddp_model_consts* c) {
     c->bound_barrier_weight = 0.0;           // off: the reference's bound barriers are commented out (ddp.py:203-208)
     c->bound_barrier_sharpness = 6.0;        // exp_parameter, ddp.py:182
     for (int i = 0; i < 64; ++i) { c->lower[i] = -HUGE_VAL; c->upper[i] = HUGE_VAL; }
+    c->relative_velocity_constraints = 1;    // contact_model > 1 (prb.py:166)
     return SDDP_OK;
 }
 

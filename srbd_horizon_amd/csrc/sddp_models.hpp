@@ -26,6 +26,7 @@ constexpr double kConstraintWeight = 1e6;  // ddp.py:181
 struct DevConsts {
     double dt, inv_ms, Is[9], com_z;
     double w_rz, w_rd, w_w, w_rel, w_f, w_sw, gq, w_pen, w_zmp, w_rxy, eta2;
+    double w_rv;                // weight of the relative-velocity constraints inside a foot (prb.py:166-170): w_pen, or 0 with contact_model = 1
     double d1x, d1y, d2x, d2y;  // rel_pos offsets d1 = p2 - p0, d2 = p3 - p1 (prb.py:153-154)
     double lever;
     double mu_lin, bar_w, bar_s;   // friction-cone exponential barrier (BAR models only): linearised coefficient, weight, sharpness
@@ -51,6 +52,7 @@ inline DevConsts make_dev_consts(const sddp_model_consts& c) {
     d.w_sw = c.force_scaling * c.force_scaling * c.force_switch_weight;  // prb.py:203-204
     d.gq = c.min_qddot_gain;                               // prb.py:200
     d.w_pen = kConstraintWeight;                           // ddp.py:181,:196
+    d.w_rv = c.relative_velocity_constraints ? kConstraintWeight : 0.0;   // prb.py:166: only `if contact_model > 1`
     d.w_zmp = c.zmp_tracking_gain;                         // prb.py:393
     d.eta2 = kGravity / c.lip_height;                      // prb.py:317
     d.d1x = c.feet[6] - c.feet[0];
@@ -465,7 +467,7 @@ struct SrbdModel {
             for (int q = 0; q < NRV; ++q) {
                 const int a = rv_a(q), b = rv_b(q);
                 const double ex = x[XCD + 3 * a] - x[XCD + 3 * b], ey = x[XCD + 3 * a + 1] - x[XCD + 3 * b + 1];
-                L += c.w_pen * (ex * ex + ey * ey);
+                L += c.w_rv * (ex * ex + ey * ey);
             }
         }
         return L;
@@ -677,8 +679,9 @@ struct SrbdModel {
                 for (int q = 0; q < NRV; ++q) {
                     const int a = rv_a(q), b = rv_b(q);
                     const double ex = x[XCD + 3 * a] - x[XCD + 3 * b], ey = x[XCD + 3 * a + 1] - x[XCD + 3 * b + 1];
-                    g[XCD + 3 * a] += sp * ex; g[XCD + 3 * b] -= sp * ex;
-                    g[XCD + 3 * a + 1] += sp * ey; g[XCD + 3 * b + 1] -= sp * ey;
+                    const double sr = 2 * c.w_rv;
+                    g[XCD + 3 * a] += sr * ex; g[XCD + 3 * b] -= sr * ex;
+                    g[XCD + 3 * a + 1] += sr * ey; g[XCD + 3 * b + 1] -= sr * ey;
                 }
             }
             if (BAR) (void)bound_cost(c, x, u, g, rec + REC_BB);   // bound barrier (off: zeros): gradient into g, GN Hessian diagonal into the record
@@ -871,8 +874,8 @@ struct SrbdModel {
                     break;
                 case V_CD:
                     if (stage && ai < 2) {
-                        if (ci == cj) { const double sw = p_sw(p, ci); v = 2 * c.w_pen * (double(rv_count(ci)) + sw * sw); }
-                        else if (rv_paired(ci, cj)) v = -2 * c.w_pen;
+                        if (ci == cj) { const double sw = p_sw(p, ci); v = 2 * c.w_rv * double(rv_count(ci)) + 2 * c.w_pen * sw * sw; }
+                        else if (rv_paired(ci, cj)) v = -2 * c.w_rv;
                     }
                     break;
                 case V_CDD: if (stage && ci == cj) v = 2 * c.gq; break;
@@ -944,7 +947,7 @@ struct SrbdModel {
     __device__ static double lam_stage(const DevConsts& c, int mrow) {
         const int m = erow(mrow);
         if (m < 6) return 2 * c.gq;
-        return (CS && m >= 10) ? 2 * c.w_pen : 0.0;
+        return (CS && m >= 10) ? 2 * c.w_rv : 0.0;
     }
     // diagonal of the Hessian: constant parts and the kind of parameter-dependent part (0 none, 1 orientation gain,
     // 2 force switch, 3 contact-velocity switch)
@@ -1221,8 +1224,8 @@ struct SrbdModel {
                 val = 2 * c.gq * c.inv_ms * c.inv_ms;
             } else {
                 const int e2 = e - 3 * NFF, comp = e2 / (NC + NRV), t = e2 % (NC + NRV);
-                if (t < NC) { row = col = XCD + 3 * t + comp; val = 2 * c.w_pen * double(rv_count(t)); }
-                else { const int q = t - NC; row = XCD + 3 * rv_b(q) + comp; col = XCD + 3 * rv_a(q) + comp; val = -2 * c.w_pen; }
+                if (t < NC) { row = col = XCD + 3 * t + comp; val = 2 * c.w_rv * double(rv_count(t)); }
+                else { const int q = t - NC; row = XCD + 3 * rv_b(q) + comp; col = XCD + 3 * rv_a(q) + comp; val = -2 * c.w_rv; }
             }
             const double q0 = Q.at(row, col) + val;
             Q.at(row, col) = q0;
@@ -1308,7 +1311,7 @@ struct LipModel {
 #pragma unroll
         for (int b = 0; b < NC; b += 2) {
             const double ex = x[XCD + 3 * b] - x[XCD + 3 * b + 3], ey = x[XCD + 3 * b + 1] - x[XCD + 3 * b + 4];
-            L += c.w_pen * (ex * ex + ey * ey);
+            L += c.w_rv * (ex * ex + ey * ey);
         }
         if (k >= 1) L += state_cost(c, x, p);
         const double dt = c.dt;
@@ -1378,8 +1381,9 @@ struct LipModel {
 #pragma unroll
             for (int b = 0; b < NC; b += 2) {
                 const double ex = x[XCD + 3 * b] - x[XCD + 3 * b + 3], ey = x[XCD + 3 * b + 1] - x[XCD + 3 * b + 4];
-                g[XCD + 3 * b] += sp * ex; g[XCD + 3 * b + 3] -= sp * ex;
-                g[XCD + 3 * b + 1] += sp * ey; g[XCD + 3 * b + 4] -= sp * ey;
+                const double sr = 2 * c.w_rv;
+                g[XCD + 3 * b] += sr * ex; g[XCD + 3 * b + 3] -= sr * ex;
+                g[XCD + 3 * b + 1] += sr * ey; g[XCD + 3 * b + 4] -= sr * ey;
             }
         }
 #pragma unroll
@@ -1445,8 +1449,8 @@ struct LipModel {
             if (state) v = 2 * c.w_rd;
         } else if (cli == V_CD && clj == V_CD) {
             if (stage && ai < 2) {
-                if (ci == cj) { const double sw = p_sw(p, ci); v = 2 * c.w_pen * (1.0 + sw * sw); }
-                else if (ci / 2 == cj / 2) v = -2 * c.w_pen;
+                if (ci == cj) { const double sw = p_sw(p, ci); v = 2 * c.w_rv + 2 * c.w_pen * sw * sw; }
+                else if (ci / 2 == cj / 2) v = -2 * c.w_rv;
             }
         } else if (cli == V_Z && clj == V_Z) {
             if (stage) v = 2 * c.w_zmp + e4;
@@ -1492,7 +1496,7 @@ struct LipModel {
         if (m < 2) return 0.0;
         if (m < 5) return 2 * c.w_zmp;
         if (m < 8) return 2 * c.gq;
-        return m >= 12 ? 2 * c.w_pen : 0.0;
+        return m >= 12 ? 2 * c.w_rv : 0.0;
     }
     __device__ static double dg_state(const DevConsts& c, int i) {
         int cls, ci, ax;

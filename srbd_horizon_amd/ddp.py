@@ -233,8 +233,20 @@ class DDPSolver:
                 raise NotImplementedError(f"model {prb.model} has ONE gain {ckey} for {len(vals)} residuals; got {sorted(set(vals))}")
             consts[ckey] = vals[0]
         eq_names = [c.getName() for c in self.equality_constraints]
-        if sorted(eq_names) != sorted(table["eq"]):
-            raise NotImplementedError(f"model {prb.model} hard-wires the equality constraints {table['eq']}; the problem holds {eq_names}")
+        # the relative-velocity constraints inside a foot are a runtime switch of the model (prb.py:166 declares them only
+        # `if contact_model > 1`): all of them or none
+        rel = [n for n in table["eq"] if n.startswith("relative_vel_")]
+        have_rel = [n for n in eq_names if n.startswith("relative_vel_")]
+        if rel and not have_rel:
+            consts["relative_velocity_constraints"] = 0
+            expected = [n for n in table["eq"] if n not in rel]
+        else:
+            if rel:
+                consts["relative_velocity_constraints"] = 1
+            expected = table["eq"]
+        if sorted(eq_names) != sorted(expected):
+            raise NotImplementedError(f"model {prb.model} implements the equality constraints {table['eq']} (the relative_vel_* ones "
+                                      f"all or none); the problem holds {eq_names}")
         for c in self.equality_constraints:
             if c.getNodes() != list(range(0, ns + 1)):
                 raise NotImplementedError(f"constraint {c.getName()!r}: only the default node range is implemented")

@@ -50,7 +50,8 @@ def quat_inverse(q):
 
 
 def _consts(robot: RobotModel, prm: dict, dt: float, feet) -> dict:
-    return dict(m=robot.m, I=np.asarray(robot.I), com=np.asarray(robot.com), feet=np.asarray(feet), dt=dt,
+    return dict(relative_velocity_constraints=int(prm["contact_model"] > 1),      # prb.py:166: `if contact_model > 1`
+                m=robot.m, I=np.asarray(robot.I), com=np.asarray(robot.com), feet=np.asarray(feet), dt=dt,
                 force_scaling=1000.0, r_tracking_gain=prm["r_tracking_gain"], rdot_tracking_gain=prm["rdot_tracking_gain"],
                 w_tracking_gain=prm["w_tracking_gain"], rel_pos_gain=prm["rel_position_gain"],
                 force_switch_weight=prm["force_switch_weight"], min_qddot_gain=prm["min_qddot_gain"],
@@ -103,7 +104,8 @@ def _declare_srbd_terms(prb, prm, ns, nc, contact_model, with_contact_states: bo
 class SRBDProblem:
     """prb.py:16-246 -- nx = 37, nu = 24, np = 19 with the launch file's contact_model=2, number_of_legs=2 (model "srbd37");
     nx = 61, nu = 48, np = 27 with the defaults in the code, contact_model=4, number_of_legs=2 (prb.py:39-40; model "srbd61",
-    pass params={"contact_model": 4})."""
+    pass params={"contact_model": 4}).  number_of_legs=4 with contact_model=1 (four point feet, nc = 4) is the srbd37 layout
+    without the relative-velocity constraints, which prb.py:166 only adds `if contact_model > 1`."""
 
     def createSRBDProblem(self, ns, T, robot: RobotModel | None = None, params: dict | None = None):
         robot = robot or RobotModel()
@@ -111,9 +113,11 @@ class SRBDProblem:
         prb = Problem(ns)
         contact_model, number_of_legs = prm["contact_model"], prm["number_of_legs"]
         nc = number_of_legs * contact_model
-        if number_of_legs != 2 or contact_model not in (2, 4):
-            raise ValueError("analytic models exist for number_of_legs=2 with contact_model=2 (srbd37, the launch file's) and "
-                             "contact_model=4 (srbd61, the default in prb.py:39); the problem indexes feet 0..3 (prb.py:153-154)")
+        if (number_of_legs, contact_model) not in ((2, 2), (2, 4), (4, 1)):
+            raise ValueError("analytic models exist for number_of_legs=2 with contact_model=2 (srbd37, the launch file's) or "
+                             "contact_model=4 (srbd61, the default in prb.py:39), and for number_of_legs=4 with contact_model=1 (four "
+                             "point feet: the srbd37 layout without the relative-velocity constraints of prb.py:166-170); the "
+                             "problem indexes feet 0..3 (prb.py:153-154)")
         r = prb.createStateVariable("r", 3)                                   # prb.py:32
         o = prb.createStateVariable("o", 4)                                   # prb.py:33
         q = Aggregate(); q.addVariable(r); q.addVariable(o)

@@ -56,11 +56,12 @@ def _force_res(cst, f, sw):
     return [*(g1 * f), *(g2 * (1 - sw) * f)]
 
 
-def _penalties(cs, cds, cref, sw):
-    """prb.py:166-170 (relative velocities inside a foot: contact_model = nc / 2 points per foot) and :179-181"""
+def _penalties(cs, cds, cref, sw, rel_vel=True):
+    """prb.py:166-170 (relative velocities inside a foot: contact_model = nc / 2 points per foot; none with contact_model = 1,
+    i.e. number_of_legs = 4 point feet: rel_vel False) and :179-181"""
     g = sp.sqrt(1e6)
     nc = len(cs)
-    cm = nc // 2
+    cm = nc // 2 if rel_vel else 1
     out = []
     for i in range(1, cm):
         out += [*(g * (cds[0][0:2, 0] - cds[i][0:2, 0]))]
@@ -119,7 +120,8 @@ def _build(name, cst):
         ires = [*(sp.sqrt(cst.min_qddot_gain) * sp.Matrix([*rddot, *wdot, *[e for c in cdd for e in c]]))]
         for i in range(nc):
             ires += _force_res(cst, fs[i], p[8 + 2 * i])
-        ires += _penalties(cs, cds, [p[7 + 2 * i] for i in range(nc)], [p[8 + 2 * i] for i in range(nc)])
+        ires += _penalties(cs, cds, [p[7 + 2 * i] for i in range(nc)], [p[8 + 2 * i] for i in range(nc)],
+                           getattr(cst, "relative_velocity_constraints", True))
     else:
         r, rd = x[0:3, 0], x[15:18, 0]
         cs = [x[3 + 3 * i:6 + 3 * i, 0] for i in range(4)]
@@ -135,7 +137,8 @@ def _build(name, cst):
                 *(sp.sqrt(cst.rdot_tracking_gain) * (rd - p[0:3, 0]))] + _relpos(cst, cs)
         ires = [*(sp.sqrt(cst.zmp_tracking_gain) * (z - mean_c)),
                 *(sp.sqrt(cst.min_qddot_gain) * sp.Matrix([*rddot, *cdd[0], *cdd[1], *cdd[2], *cdd[3]]))]
-        ires += _penalties(cs, cds, [p[3 + 2 * i] for i in range(4)], [p[4 + 2 * i] for i in range(4)])
+        ires += _penalties(cs, cds, [p[3 + 2 * i] for i in range(4)], [p[4 + 2 * i] for i in range(4)],
+                           getattr(cst, "relative_velocity_constraints", True))
     f = x + dt * xdot
     z_all = sp.Matrix([*x, *u])
     out = {}
@@ -153,10 +156,10 @@ def _build(name, cst):
 
 
 @functools.lru_cache(maxsize=None)
-def second_order_symbolic(name, inertia_mode=0, lever_sign=1.0):
+def second_order_symbolic(name, inertia_mode=0, lever_sign=1.0, rel_vel=True):
     """lambda (x, u, p, vp) -> Hessian_z[vp.f + L_k] - 2 J^T J  (stage node k >= 1: input and state residuals), symbolic."""
     from oracle.models import RobotConsts
-    sym = _build(name, RobotConsts(inertia_mode=inertia_mode, lever_sign=lever_sign))
+    sym = _build(name, RobotConsts(inertia_mode=inertia_mode, lever_sign=lever_sign, relative_velocity_constraints=rel_vel))
     x, u, p, f, ires_m, sres_m, z_all = sym["_sym"]
     vp = sp.Matrix(sp.symbols(f"v0:{len(x)}"))
     res = sp.Matrix([*ires_m, *sres_m])
@@ -173,9 +176,9 @@ def second_order_symbolic(name, inertia_mode=0, lever_sign=1.0):
     return sp.lambdify((list(x), list(u), list(p), list(vp)), H, "numpy", cse=True)
 
 @functools.lru_cache(maxsize=None)
-def symbolic(name, inertia_mode=0, lever_sign=1.0):   # the consts object is returned so that callers can key caches on it
+def symbolic(name, inertia_mode=0, lever_sign=1.0, rel_vel=True):   # the consts object is returned so that callers can key caches on it
     from oracle.models import RobotConsts
-    cst = RobotConsts(inertia_mode=inertia_mode, lever_sign=lever_sign)
+    cst = RobotConsts(inertia_mode=inertia_mode, lever_sign=lever_sign, relative_velocity_constraints=rel_vel)
     return _build(name, cst), cst
 
 

@@ -105,3 +105,31 @@ def test_pyddp_shaped_module_checks_its_arguments():
         pyddp.DdpSolver(13, 6, [lambda x, u: x] * 30, L_list, L_term, o)
     with pytest.raises(ValueError):
         pyddp.DdpSolver(13, 6, f_list[:-1], L_list, L_term, o)
+
+
+def test_four_point_feet_is_the_srbd37_layout_without_relative_velocity_constraints():
+    """number_of_legs = 4 x contact_model = 1 runs in the reference (prb.py:39-41: nc = 4) and declares NO relative_vel_*
+    constraint (prb.py:166: `if contact_model > 1`).  Here: the srbd37 model with its runtime switch off -- through the builder
+    and, equally, by removing those constraints from a contact_model = 2 problem; a partial set raises."""
+    pb = SRBDProblem(); prb = pb.createSRBDProblem(NS, 1.0, params=dict(number_of_legs=4, contact_model=1))
+    assert prb.model == "srbd37" and pb.nc == 4 and pb.contact_model == 1
+    names = list(prb.function_container.getCnstr())
+    assert not any(n.startswith("relative_vel_") for n in names) and len(names) == 8       # cz_tracking_i, cdotxy_tracking_i
+    assert prb.model_consts["relative_velocity_constraints"] == 0
+    c = _adapter(prb)._model_consts_from_functions()
+    assert c["relative_velocity_constraints"] == 0
+    assert pb.getInitialState().shape == (37,) and pb.getStaticInput().shape == (24,)      # prb.py:224-246 literals
+    # the launch file's configuration keeps them
+    pb2 = SRBDProblem(); prb2 = pb2.createSRBDProblem(NS, 1.0)
+    assert _adapter(prb2)._model_consts_from_functions()["relative_velocity_constraints"] == 1
+    # ... and dropping them from its container by hand is the same switch
+    for n in ("relative_vel_left_1", "relative_vel_right_3"):
+        prb2.removeConstraint(n)
+    assert _adapter(prb2)._model_consts_from_functions()["relative_velocity_constraints"] == 0
+    pb3 = SRBDProblem(); prb3 = pb3.createSRBDProblem(NS, 1.0)
+    prb3.removeConstraint("relative_vel_left_1")                                           # one of two: no such model
+    with pytest.raises(NotImplementedError):
+        _adapter(prb3)._model_consts_from_functions()
+    for bad in (dict(number_of_legs=4, contact_model=2), dict(number_of_legs=1, contact_model=4), dict(number_of_legs=2, contact_model=3)):
+        with pytest.raises(ValueError):
+            SRBDProblem().createSRBDProblem(NS, 1.0, params=bad)

@@ -1,0 +1,75 @@
+"""number_of_legs = 4 x contact_model = 1 (prb.py:39-41 takes any pair; prb.py:166 then declares no relative-velocity constraint):
+the srbd37 / lip30 kernels with `sddp_model_consts.relative_velocity_constraints = 0` against both oracles -- per-knot evaluation,
+converged solves, the builder surface."""
+import numpy as np
+import pytest
+
+from oracle import cport, ddp as oddp, models as omodels
+from srbd_horizon_amd import workload
+from srbd_horizon_amd.ddp import DDPSolver
+from srbd_horizon_amd.engine import DdpEngine, eval_knots
+from srbd_horizon_amd.prb import SRBDProblem
+
+pytestmark = pytest.mark.gpu
+OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
+
+
+@pytest.mark.parametrize("model", ["srbd37", "lip30"])
+def test_knots_without_relative_velocity_rows(model):
+    N = 20
+    cst = omodels.RobotConsts(relative_velocity_constraints=False)
+    m = omodels.make_model(model, cst)
+    rng = np.random.default_rng(3)
+    ks = np.array([0, 1, 5, N - 1, N], dtype=np.int32)
+    P0 = m.default_params(N)
+    X = np.stack([m.initial_state() + 0.05 * rng.standard_normal(m.nx) for _ in ks])
+    U = np.stack([m.static_input() + 0.05 * rng.standard_normal(m.nu) for _ in ks])
+    P = np.stack([P0[min(k, N)] + 0.02 * rng.standard_normal(m.np_) for k in ks])
+    f, F, H, g, L = eval_knots(model, N, ks, X, U, P, consts=dict(relative_velocity_constraints=0))
+    f1, F1, H1, g1, L1 = eval_knots(model, N, ks, X, U, P)
+    assert np.max(np.abs(H - H1)) > 1.0                                   # the switch does something (2e6 on the cdot block)
+    for i, k in enumerate(ks):
+        term = k == N
+        Lo, lx, lu, lxx, lux, luu = m.cost_derivs(X[i], None if term else U[i], P[i], int(k))
+        assert abs(L[i] - Lo) <= 1e-11 * max(1.0, abs(Lo))
+        if term:
+            np.testing.assert_allclose(g[i, :m.nx], lx, rtol=1e-11, atol=1e-9 * max(1, np.max(np.abs(lx))))
+            np.testing.assert_allclose(H[i, :m.nx, :m.nx], lxx, rtol=1e-11, atol=1e-7)
+        else:
+            np.testing.assert_allclose(f[i], m.f(X[i], U[i], P[i]), rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(g[i], np.concatenate([lx, lu]), rtol=1e-11, atol=1e-9 * max(1, np.max(np.abs(lx))))
+            np.testing.assert_allclose(H[i], np.block([[lxx, lux.T], [lux, luu]]), rtol=1e-11, atol=1e-7)
+
+
+@pytest.mark.parametrize("model,N,B", [("srbd37", 20, 24), ("srbd37", 60, 6), ("lip30", 20, 16)])
+def test_solves_without_relative_velocity_rows_match_the_c_oracle(model, N, B):
+    batch = workload.make_batch(model, N, np.arange(B) + 3)
+    consts = dict(batch["consts"], relative_velocity_constraints=0)
+    eng = DdpEngine(model, N, B, opts=OPTS, consts=consts)
+    eng.set_initial_state(batch["x0"]); eng.set_x_warmstart(batch["xs"]); eng.set_u_warmstart(batch["us"])
+    x, u = eng.solve(batch["params"])
+    xo, uo, so = cport.solve_batch(omodels.RobotConsts(**consts), oddp.DdpOptions(**OPTS), batch["x0"], batch["params"], batch["xs"],
+                                   batch["us"], threads=4, model=model)
+    np.testing.assert_array_equal(eng.stats["iters"], so[:, 1].astype(int))
+    assert eng.stats["converged"].all()
+    assert np.max(np.abs(x - xo)) <= 1e-6 and np.max(np.abs(u - uo)) <= 1e-6
+    np.testing.assert_allclose(eng.stats["cost"], so[:, 0], rtol=1e-9)
+
+
+def test_builder_surface_with_four_point_feet():
+    """createSRBDProblem(number_of_legs = 4, contact_model = 1) -> DDPSolver -> solve, as dsrbd_example.py:54-59 does."""
+    ns, T = 20, 1.0
+    pb = SRBDProblem(); prb = pb.createSRBDProblem(ns, T, params=dict(number_of_legs=4, contact_model=1))
+    solver = DDPSolver(prb, OPTS)
+    x0 = pb.getInitialState(); x0[0] += 0.01; x0[2] += 0.01
+    solver.setInitialState(x0)
+    solver.set_u_warmstart(np.repeat(pb.getStaticInput()[:, None], ns, axis=1))
+    assert solver.solve()
+    sol = solver.getSolutionDict()
+    m = omodels.make_model("srbd37", omodels.RobotConsts(relative_velocity_constraints=False))
+    P = prb.parameter_matrix()
+    r = oddp.solve(m, x0, P, np.repeat(x0[None], ns + 1, axis=0), np.repeat(pb.getStaticInput()[None], ns, axis=0), oddp.DdpOptions(**OPTS))
+    assert r.converged and solver.stats["iters"] == r.iters
+    assert np.max(np.abs(sol["x_opt"].T - r.xs)) <= 1e-6 and np.max(np.abs(sol["u_opt"].T - r.us)) <= 1e-6
+    # the four feet may now move apart inside a "foot": cdot0 - cdot1 is free (it is pinned to 0 with contact_model = 2)
+    assert sol["cdot0"].shape == (3, ns + 1)

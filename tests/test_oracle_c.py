@@ -173,3 +173,20 @@ def test_resumed_oracle_solve_continues_the_same_path():
     xr, ur, sr, _ = cport.solve_trace(cst, oddp.DdpOptions(**opts), batch["x0"][0], batch["params"][0], xk[0], uk[0], resume=resume)
     assert int(sr[1]) + k == int(sf[0, 1]) and int(sr[2]) == 1
     assert np.max(np.abs(xr - xf[0])) <= 1e-9 and np.max(np.abs(ur - uf[0])) <= 1e-9
+
+
+@pytest.mark.parametrize("model,N", [("srbd37", 20), ("lip30", 20)])
+def test_c_oracle_without_relative_velocity_constraints_matches_numpy(model, N):
+    """number_of_legs = 4 x contact_model = 1 (prb.py:166: no relative_vel_* constraints): the flag in both oracles."""
+    batch = workload.make_batch(model, N, [2, 9])
+    cst = omodels.RobotConsts(**dict(batch["consts"], relative_velocity_constraints=False))
+    m = omodels.make_model(model, cst)
+    opts = oddp.DdpOptions(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
+    xs, us, st = cport.solve_batch(cst, opts, batch["x0"], batch["params"], batch["xs"], batch["us"], model=model)
+    xs1, us1, st1 = cport.solve_batch(omodels.RobotConsts(**batch["consts"]), opts, batch["x0"], batch["params"], batch["xs"], batch["us"], model=model)
+    for b in range(2):
+        r = oddp.solve(m, batch["x0"][b], batch["params"][b], batch["xs"][b], batch["us"][b], opts)
+        assert int(st[b, 1]) == r.iters and bool(st[b, 2]) == r.converged
+        assert np.max(np.abs(xs[b] - r.xs)) <= 1e-8 and np.max(np.abs(us[b] - r.us)) <= 1e-8
+    if model == "srbd37":
+        assert np.max(np.abs(xs - xs1)) > 1e-6          # and it is another problem than the one with the constraints

@@ -16,12 +16,13 @@ def _rand_point(m, rng, N=20):
     return x, u, p
 
 
-CASES = [("srbd13", 0, 1.0), ("srbd13", 0, -1.0), ("srbd37", 0, 1.0), ("lip30", 0, 1.0), ("srbd61", 0, 1.0)]
+CASES = [("srbd13", 0, 1.0, True), ("srbd13", 0, -1.0, True), ("srbd37", 0, 1.0, True), ("lip30", 0, 1.0, True), ("srbd61", 0, 1.0, True),
+         ("srbd37", 0, 1.0, False), ("lip30", 0, 1.0, False)]      # False: number_of_legs = 4 x contact_model = 1, no relative-velocity rows
 
 
-@pytest.mark.parametrize("name,imode,lever", CASES)
-def test_dynamics_and_costs_match_sympy(name, imode, lever):
-    sym, cst = sym_models.symbolic(name, imode, lever)
+@pytest.mark.parametrize("name,imode,lever,rel_vel", CASES)
+def test_dynamics_and_costs_match_sympy(name, imode, lever, rel_vel):
+    sym, cst = sym_models.symbolic(name, imode, lever, rel_vel)
     m = models.make_model(name, cst)
     rng = np.random.default_rng(7)
     for _ in range(3):
