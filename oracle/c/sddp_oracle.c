@@ -22,11 +22,17 @@ typedef struct {
     int inertia_mode;
     double box_w, box_s, lower[64], upper[64];   /* bound barrier (oracle/models.py _bound_rows, ddp.py:203-208): off when box_w == 0 */
     int rv;                        /* relative-velocity constraints inside a foot present (prb.py:166: `if contact_model > 1`) */
+    /* user-declared linear residual rows (oracle/models.py WithLinearRows): xr_on: the parameter vector is NXR columns wider and
+     * row j = sqrt(xw[j]) (xa[j] . z - p[np + j] - xc[j]), kind 0 "state" (nodes 1..N) / 1 "stage" (nodes 0..N-1); nz entries of xa used */
+    int xr_on, xr_n, xkind[8];
+    double xw[8], xc[8], xa[8][128];
 } consts_t;
+#define NXR 8
 
 /* packed constants from Python: m, I[9], com_z, dt, force_scaling, r_gain, rdot_gain, w_gain, fsw, qddot, minf, inertia_mode, lever,
  * friction_cone_coefficient, friction_barrier_weight, friction_barrier_sharpness, rel_pos_gain, zmp_gain, lip_height, feet[12],
- * bound_barrier_weight, bound_barrier_sharpness, lower[64], upper[64], relative_velocity_constraints */
+ * bound_barrier_weight, bound_barrier_sharpness, lower[64], upper[64], relative_velocity_constraints,
+ * xr_on, xr_n, then per extra row (8 of them): kind, w, const, a[128] */
 static void unpack_consts(const double* c, consts_t* k) {
     const double m = c[0], fs = c[12];
     k->inv_ms = fs / m;
@@ -41,8 +47,30 @@ static void unpack_consts(const double* c, consts_t* k) {
     k->box_w = c[39]; k->box_s = c[40];
     for (int i = 0; i < 64; ++i) { k->lower[i] = c[41 + i]; k->upper[i] = c[105 + i]; }
     k->rv = c[169] != 0.0;
+    k->xr_on = c[170] != 0.0; k->xr_n = (int)c[171];
+    for (int j = 0; j < 8; ++j) {
+        const double* q = c + 172 + j * 131;
+        k->xkind[j] = (int)q[0]; k->xw[j] = q[1]; k->xc[j] = q[2];
+        for (int i = 0; i < 128; ++i) k->xa[j][i] = q[3 + i];
+    }
 }
 
+/* the user rows of node k (u == NULL: terminal) appended to r / J (row stride nz) from row n on; pref = the node's NXR reference columns */
+static int xr_rows(const consts_t* c, int nx, int nu, const double* x, const double* u, const double* pref, int k, double* r, double* J, int nz, int n) {
+    if (!c->xr_on) return n;
+    for (int j = 0; j < c->xr_n; ++j) {
+        const int active = c->xkind[j] == 0 ? (k >= 1) : (u != NULL);
+        if (!active) continue;
+        const double g = sqrt(c->xw[j]);
+        double e = -pref[j] - c->xc[j];
+        for (int i = 0; i < nx; ++i) e += c->xa[j][i] * x[i];
+        if (u) for (int i = 0; i < nu; ++i) e += c->xa[j][nx + i] * u[i];
+        r[n] = g * e;
+        if (J) { for (int i = 0; i < nz; ++i) J[n * nz + i] = (i < nx || u) ? g * c->xa[j][i] : 0.0; }
+        ++n;
+    }
+    return n;
+}
 static void cross(const double* a, const double* b, double* o) {
     o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
 }

@@ -52,8 +52,32 @@ def pack_consts(cst, model=None):
                      cst.friction_cone_coefficient, cst.friction_barrier_weight, cst.friction_barrier_sharpness,
                      cst.rel_pos_gain, cst.zmp_tracking_gain, cst.lip_height, *feet,
                      cst.bound_barrier_weight, cst.bound_barrier_sharpness, *_bounds64(cst.lower, -np.inf), *_bounds64(cst.upper, np.inf),
-                     float(bool(getattr(cst, "relative_velocity_constraints", True)))],
+                     float(bool(getattr(cst, "relative_velocity_constraints", True))), *_extra_rows(cst, model)],
                     dtype=np.float64)
+
+
+NXR = 8
+
+
+def _extra_rows(cst, model):
+    """xr_on, xr_n, then 8 x (kind, w, const, a[128]) (oracle/c/sddp_oracle.c unpack_consts)"""
+    rows = list(getattr(cst, "extra_rows", None) or ())
+    out = [float(bool(rows)), float(len(rows))]
+    nz = sum(DIMS[model or "srbd13"][:2])
+    for j in range(NXR):
+        a = np.zeros(128)
+        if j < len(rows):
+            r = rows[j]
+            a[:nz] = np.asarray(r["a"], dtype=float)
+            out += [0.0 if r["kind"] == "state" else 1.0, float(r["w"]), float(r.get("const", 0.0)), *a]
+        else:
+            out += [0.0, 0.0, 0.0, *a]
+    return out
+
+
+def n_params(cst, model):
+    """parameter columns per node: the model's own, + NXR reference columns when user rows are declared"""
+    return DIMS[model][2] + (NXR if getattr(cst, "extra_rows", None) else 0)
 
 
 def _bounds64(b, fill):
@@ -87,6 +111,7 @@ def solve_batch(cst, opts, x0, P, xs, us, threads=1, model="srbd13", variant=Non
     us = np.ascontiguousarray(us, dtype=np.float64).copy()
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     P = np.ascontiguousarray(P, dtype=np.float64)
+    npar = n_params(cst, model)
     assert xs.shape == (B, N + 1, nx) and us.shape == (B, N, nu) and x0.shape == (B, nx) and P.shape == (B, N + 1, npar)
     stats = np.zeros((B, 8))
     cp, op = pack_consts(cst, model), pack_opts(opts)
@@ -121,6 +146,7 @@ def solve_trace(cst, opts, x0, P, xs, us, model="srbd13", variant=None, cap=256,
     nx, nu, npar = DIMS[model]
     xs = np.ascontiguousarray(xs, dtype=np.float64).copy(); us = np.ascontiguousarray(us, dtype=np.float64).copy()
     x0 = np.ascontiguousarray(x0, dtype=np.float64); P = np.ascontiguousarray(P, dtype=np.float64)
+    npar = n_params(cst, model)
     assert xs.shape == (N + 1, nx) and us.shape == (N, nu) and x0.shape == (nx,) and P.shape == (N + 1, npar)
     W = lib.oracle_trace_width()
     tr = np.zeros((cap, W)); stats = np.zeros(8)

@@ -71,6 +71,11 @@ class RobotConsts:
     # prb.py:166-170: the relative-velocity constraints inside a foot exist only `if contact_model > 1`.  False = the same state
     # layout with number_of_legs = 4 point feet (contact_model = 1, nc = 4): no such rows
     relative_velocity_constraints: bool = True
+    # User-declared LINEAR residual rows (ddp.py:183-196 sums whatever residual the function container holds; the analytic models
+    # take up to NXR = 8 extra rows of the form sqrt(w) (a . z - ref), z = [x u]): tuple of dict(a [nz], w, kind "state" (nodes
+    # 1..N) | "stage" (nodes 0..N-1), const).  Row j's per-knot reference is parameter column np + j of a parameter vector that is
+    # NXR columns wider than the model's own; ref = p[np + j] + const.
+    extra_rows: tuple | None = None
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -834,5 +839,66 @@ class LIP30(Model):
 MODELS = {"srbd13": SRBD13, "srbd37": SRBD37, "lip30": LIP30, "srbd61": SRBD61}
 
 
+NXR = 8      # extra linear residual rows an "_x" build carries (= extra parameter columns)
+
+
+class WithLinearRows(Model):
+    """A model plus user-declared linear residual rows (RobotConsts.extra_rows): the parameter vector is NXR columns wider, the
+    last NXR columns are the rows' per-knot references.  Dynamics untouched."""
+
+    def __init__(self, base: Model):
+        self.base, self.cst = base, base.cst
+        self.name = base.name
+        self.nx, self.nu, self.npb = base.nx, base.nu, base.np_
+        self.np_ = base.np_ + NXR
+        rows = list(self.cst.extra_rows or ())
+        if len(rows) > NXR:
+            raise ValueError(f"at most {NXR} extra rows")
+        for r in rows:
+            a = np.asarray(r["a"], dtype=float)
+            if a.shape != (self.nx + self.nu,) or r["kind"] not in ("state", "stage") or not (r["w"] >= 0.0):
+                raise ValueError("extra row: a [nx + nu], w >= 0, kind 'state' | 'stage'")
+            if r["kind"] == "state" and np.any(a[self.nx:] != 0.0):
+                raise ValueError("a 'state' row (nodes 1..N, terminal node included) cannot touch the inputs")
+        self.rows = rows
+
+    def f(self, x, u, p):
+        return self.base.f(x, u, p[:self.npb])
+
+    def f_jac(self, x, u, p):
+        return self.base.f_jac(x, u, p[:self.npb])
+
+    def residual_jac(self, x, u, p, k):
+        r, Jx, Ju = self.base.residual_jac(x, u, p[:self.npb], k)
+        rr, jx, ju = [r], [Jx], [Ju]
+        for j, row in enumerate(self.rows):
+            active = (k >= 1) if row["kind"] == "state" else (u is not None)
+            if not active:
+                continue
+            a = np.asarray(row["a"], dtype=float)
+            g = np.sqrt(row["w"])
+            z = np.concatenate([x, u if u is not None else np.zeros(self.nu)])
+            rr.append(np.array([g * (a @ z - p[self.npb + j] - row.get("const", 0.0))]))
+            jx.append(g * a[None, :self.nx]); ju.append(g * a[None, self.nx:])
+        return np.concatenate(rr), np.vstack(jx), np.vstack(ju)
+
+    def second_order_ux(self, x, u, p, vp):
+        return self.base.second_order_ux(x, u, p[:self.npb], vp)
+
+    def second_order_full(self, x, u, p, k, vp):
+        return self.base.second_order_full(x, u, p[:self.npb], k, vp)
+
+    def initial_state(self):
+        return self.base.initial_state()
+
+    def static_input(self):
+        return self.base.static_input()
+
+    def default_params(self, N):
+        P = self.base.default_params(N)
+        return np.hstack([P, np.zeros((P.shape[0], NXR))])
+
+
 def make_model(name: str, cst: RobotConsts | None = None) -> Model:
-    return MODELS[name](cst)
+    m = MODELS[name](cst)
+    return WithLinearRows(m) if (cst is not None and cst.extra_rows) else m
