@@ -111,7 +111,21 @@ typedef struct sddp_model_consts {
      * 1 (default): they are there -- contact_model = 2 (srbd37, lip30) or 4 (srbd61).  0: the same state layout with POINT feet,
      * number_of_legs = 4 x contact_model = 1 (nc = 4 on the srbd37 / lip30 build): no such rows.  (v9) */
     int    relative_velocity_constraints;
+    /* User-declared LINEAR residual rows.  The reference's stage / terminal costs sum WHATEVER residual its function container
+     * holds (ddp.py:183-196, :216-226); the analytic models hard-wire prb.py's terms, and take on top up to SDDP_MAX_EXTRA rows
+     *     r_j = sqrt(extra_weight[j]) * ( extra_a[j] . z  -  ( p[np + j] + extra_const[j] ) ),      z = [x u],
+     * extra_kind[j] 0: a state row, active on nodes 1..N like prb.py's tracking terms (terminal node included; its coefficients on
+     * the inputs must be 0), 1: a stage row, nodes 0..N-1 like min_qddot.  n_extra > 0 selects the model's "_x" build (srbd13,
+     * srbd37, lip30; plain build only: no barrier, no second_order = 2), whose parameter vector is SDDP_MAX_EXTRA columns wider
+     * than sddp_model_dims says: columns np .. np + 7 of every node are the per-knot references of rows 0..7 (unused ones: 0);
+     * sddp_handle_dims reports the handle's width.  (v9) */
+    int    n_extra;
+    int    extra_kind[8];
+    double extra_weight[8];
+    double extra_const[8];
+    double extra_a[8 * 128];    /* row j: extra_a[128 j + i], i < nx + nu */
 } sddp_model_consts;
+#define SDDP_MAX_EXTRA 8
 
 /* per-instance solve record (what pyddp exposes only as is_converged(), ddp.py:106, plus the tic/toc of
  * dsrbd_example.py:134-136) */
@@ -138,6 +152,8 @@ typedef struct sddp_handle sddp_handle;
 
 int  sddp_abi_version(void);
 int  sddp_model_dims(int model_id, int* nx, int* nu, int* np);
+/* dimensions of THIS handle: np is SDDP_MAX_EXTRA larger than sddp_model_dims' when the handle carries user rows (n_extra > 0) */
+int  sddp_handle_dims(sddp_handle* h, int* nx, int* nu, int* np);
 void sddp_default_options(sddp_options* opts);
 void sddp_default_consts(sddp_model_consts* consts);            /* = sddp_default_consts_for(SDDP_MODEL_SRBD37, ...) */
 /* the synthetic robot as model `model_id` needs it: `feet` holds contact points 0..3 of THAT model --
@@ -244,6 +260,7 @@ int  sddp_model_step(sddp_handle* h, const double* x /*[B][nx]*/, const double* 
  * sddp_eval_knots: per-knot model evaluation (reference: CasADi evaluation of f_k / L_k and their derivatives
  * inside pyddp; problem definition prb.py:92-110, :141-204).  nk knots, node index k[i] (k==N: terminal).
  *   f_out [nk][nx], F_out [nk][nx][nx+nu] (= [fx fu]), H_out [nk][nz][nz] (GN Hessian of L), g_out [nk][nz], L_out [nk] */
+/* (with consts->n_extra > 0: p is [nk][np + SDDP_MAX_EXTRA]) */
 int  sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk, const int* k,
                      const double* x, const double* u, const double* p,
                      double* f_out, double* F_out, double* H_out, double* g_out, double* L_out);

@@ -38,7 +38,9 @@ class SddpModelConsts(C.Structure):
                 ("inertia_mode", C.c_int), ("lever_sign", C.c_double), ("friction_cone_coefficient", C.c_double),
                 ("friction_barrier_weight", C.c_double), ("friction_barrier_sharpness", C.c_double),
                 ("bound_barrier_weight", C.c_double), ("bound_barrier_sharpness", C.c_double),
-                ("lower", C.c_double * 64), ("upper", C.c_double * 64), ("relative_velocity_constraints", C.c_int)]
+                ("lower", C.c_double * 64), ("upper", C.c_double * 64), ("relative_velocity_constraints", C.c_int),
+                ("n_extra", C.c_int), ("extra_kind", C.c_int * 8), ("extra_weight", C.c_double * 8), ("extra_const", C.c_double * 8),
+                ("extra_a", C.c_double * 1024)]
 
 
 class SddpStats(C.Structure):
@@ -62,6 +64,7 @@ _vp = C.c_void_p
 SYMBOLS = {
     "sddp_abi_version": (C.c_int, []),
     "sddp_model_dims": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
+    "sddp_handle_dims": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "sddp_default_options": (None, [_P(SddpOptions)]),
     "sddp_default_consts": (None, [_P(SddpModelConsts)]),
     "sddp_default_consts_for": (C.c_int, [C.c_int, _P(SddpModelConsts)]),
@@ -111,6 +114,7 @@ INSTANCES = [
     ("srbd13", "Srbd13", "srbd13"), ("srbd13_b", "Srbd13B", "srbd13"), ("srbd13_s", "Srbd13S", "srbd13"), ("srbd13_bs", "Srbd13BS", "srbd13"),
     ("srbd37", "Srbd37", "srbd37"), ("srbd37_b", "Srbd37B", "srbd37"), ("srbd37_s", "Srbd37S", "srbd37"), ("srbd37_bs", "Srbd37BS", "srbd37"),
     ("lip30", "Lip30", "lip30"), ("srbd61", "Srbd61", "srbd61"),
+    ("srbd13_x", "Srbd13X", "srbd13"), ("srbd37_x", "Srbd37X", "srbd37"), ("lip30_x", "Lip30X", "lip30"),    # user rows (n_extra > 0)
 ]
 # Per-build compiler options.  srbd61 (one workgroup per CU, 512 registers a lane, still 1.8 KB of scratch): LLVM's
 # -sink-insts-to-avoid-spills moves hoisted loop-invariant address arithmetic back into the loops instead of spilling it:
@@ -249,8 +253,39 @@ def default_consts(model: str | None = None, **over) -> SddpModelConsts:
     return c
 
 
+MAX_EXTRA = 8
+
+
+def _set_extra_rows(c: SddpModelConsts, rows):
+    """rows: sequence of dict(a [nx + nu], w, kind "state" | "stage", const) -- user-declared linear residual rows
+    sqrt(w) (a . z - (p[np + j] + const)) (include/sddp.h extra_*); None / () clears them."""
+    rows = list(rows or ())
+    if len(rows) > MAX_EXTRA:
+        raise ValueError(f"at most {MAX_EXTRA} extra rows")
+    c.n_extra = len(rows)
+    for j in range(MAX_EXTRA):
+        c.extra_kind[j] = 0
+        c.extra_weight[j] = c.extra_const[j] = 0.0
+        for i in range(128):
+            c.extra_a[128 * j + i] = 0.0
+    for j, r in enumerate(rows):
+        a = np.asarray(r["a"], dtype=float).reshape(-1)
+        if a.size > 128:
+            raise ValueError("extra row: at most 128 coefficients")
+        if r["kind"] not in ("state", "stage"):
+            raise ValueError("extra row kind must be 'state' or 'stage'")
+        c.extra_kind[j] = 0 if r["kind"] == "state" else 1
+        c.extra_weight[j] = float(r["w"])
+        c.extra_const[j] = float(r.get("const", 0.0))
+        for i, v in enumerate(a):
+            c.extra_a[128 * j + i] = float(v)
+
+
 def set_consts(c: SddpModelConsts, **over):
     for k, v in over.items():
+        if k == "extra_rows":
+            _set_extra_rows(c, v)
+            continue
         if k in ("lower", "upper"):                    # bounds of z = [x u]: the first nx + nu entries, the rest stays unbounded
             field = getattr(c, k)
             if v is not None:

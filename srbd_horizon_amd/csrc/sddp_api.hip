@@ -30,6 +30,9 @@ const ModelOps* ops_srbd37_s();
 const ModelOps* ops_srbd37_bs();
 const ModelOps* ops_lip30();
 const ModelOps* ops_srbd61();
+const ModelOps* ops_srbd13_x();
+const ModelOps* ops_srbd37_x();
+const ModelOps* ops_lip30_x();
 
 std::string& create_error() {
     thread_local std::string e;
@@ -67,7 +70,16 @@ int alloc_cold_queue(sddp_handle* h) {
 namespace {
 
 // bar: the barrier build of the SRBD models (friction cone and / or variable bounds), so2: the full second-order build
-const ModelOps* model_ops(int id, bool bar = false, bool so2 = false) {
+const ModelOps* model_ops(int id, bool bar = false, bool so2 = false, bool xr = false) {
+    if (xr) {     // user rows: plain builds only
+        if (bar || so2) return nullptr;
+        switch (id) {
+            case SDDP_MODEL_SRBD13: return ops_srbd13_x();
+            case SDDP_MODEL_SRBD37: return ops_srbd37_x();
+            case SDDP_MODEL_LIP30: return ops_lip30_x();
+            default: return nullptr;
+        }
+    }
     switch (id) {
         case SDDP_MODEL_SRBD13: return so2 ? (bar ? ops_srbd13_bs() : ops_srbd13_s()) : (bar ? ops_srbd13_b() : ops_srbd13());
         case SDDP_MODEL_SRBD37: return so2 ? (bar ? ops_srbd37_bs() : ops_srbd37_s()) : (bar ? ops_srbd37_b() : ops_srbd37());
@@ -78,6 +90,30 @@ const ModelOps* model_ops(int id, bool bar = false, bool so2 = false) {
 }
 // models whose only build is the default one: linear-quadratic (lip30), or no barrier / second_order = 2 build instantiated (srbd61)
 bool single_build(int id) { return id == SDDP_MODEL_LIP30; }
+
+// user rows of a constants struct: validation, and the device table of DevConsts::xr
+const char* check_extra(const sddp_model_consts& c, int nx, int nu) {
+    if (c.n_extra < 0 || c.n_extra > SDDP_MAX_EXTRA) return "n_extra must be 0..8";
+    for (int j = 0; j < c.n_extra; ++j) {
+        if (c.extra_kind[j] != 0 && c.extra_kind[j] != 1) return "extra_kind must be 0 (state row) or 1 (stage row)";
+        if (!(c.extra_weight[j] >= 0.0) || !std::isfinite(c.extra_weight[j]) || !std::isfinite(c.extra_const[j])) return "extra_weight must be finite and >= 0, extra_const finite";
+        for (int i = 0; i < 128; ++i) {
+            const double v = c.extra_a[128 * j + i];
+            if (!std::isfinite(v)) return "extra_a must be finite";
+            if (i >= nx + nu && v != 0.0) return "extra_a: entries past nx + nu must be 0";
+            if (c.extra_kind[j] == 0 && i >= nx && v != 0.0) return "a state row (extra_kind 0) cannot touch the inputs: it is active at the terminal node";
+        }
+    }
+    return nullptr;
+}
+void fill_extra_table(const sddp_model_consts& c, double* t /*[kXrWords]*/) {
+    std::memset(t, 0, sizeof(double) * kXrWords);
+    for (int j = 0; j < c.n_extra; ++j) {
+        for (int i = 0; i < kXrStride; ++i) t[j * kXrStride + i] = c.extra_a[128 * j + i];
+        t[(c.extra_kind[j] == 0 ? kXrWS : kXrWG) + j] = c.extra_weight[j];
+        t[kXrC + j] = c.extra_const[j];
+    }
+}
 
 // host scratch of a call: plain malloc (no exception can cross the C boundary), freed on every return path
 struct host_buf {
@@ -150,6 +186,14 @@ int sddp_model_dims(int model_id, int* nx, int* nu, int* np) {
     return SDDP_OK;
 }
 
+int sddp_handle_dims(sddp_handle* h, int* nx, int* nu, int* np) {
+    if (!h) return SDDP_ERR_ARG;
+    if (nx) *nx = h->d.nx;
+    if (nu) *nu = h->d.nu;
+    if (np) *np = h->d.np;
+    return SDDP_OK;
+}
+
 void sddp_default_options(sddp_options* o) {
     if (!o) return;
     o->max_iters = 100;                      // ddp.py:17
@@ -212,10 +256,13 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     // barrier builds: the friction-cone barrier and / or the bound barrier
     const bool bar = consts && (consts->friction_barrier_weight > 0.0 || consts->bound_barrier_weight > 0.0) && !single_build(model_id);
     const bool so2 = opts && opts->second_order == 2 && !single_build(model_id);     // (the LIP model is linear-quadratic: nothing to add)
-    const ModelOps* ops = model_ops(model_id, bar, so2);
-    if (!ops) return fail(nullptr, SDDP_ERR_ARG, "this model has no barrier / second_order = 2 build (srbd61: default build only)");
+    const bool xr = consts && consts->n_extra != 0;
+    const ModelOps* ops = model_ops(model_id, bar, so2, xr);
+    if (!ops) return fail(nullptr, SDDP_ERR_ARG, xr ? "user rows (n_extra > 0) exist for the plain builds of srbd13, srbd37 and lip30 only (no barrier, no second_order = 2)"
+                                                    : "this model has no barrier / second_order = 2 build (srbd61: default build only)");
     const Dims d = ops->dims;
     if (N < 1 || batch < 1) return fail(nullptr, SDDP_ERR_ARG, "N and batch must be >= 1");
+    if (xr) { const char* msg = check_extra(*consts, d.nx, d.nu); if (msg) return fail(nullptr, SDDP_ERR_ARG, msg); }
     if (consts && (consts->friction_barrier_weight < 0.0 || (consts->friction_barrier_weight > 0.0 && !(consts->friction_cone_coefficient > 0.0))))
         return fail(nullptr, SDDP_ERR_ARG, "friction_barrier_weight must be >= 0 and friction_cone_coefficient > 0");
     if (consts && (consts->bound_barrier_weight < 0.0 || !std::isfinite(consts->bound_barrier_weight) ||
@@ -244,6 +291,14 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
         e = alloc((void**)&h->box_dev, sizeof(hb));
         if (e == hipSuccess) e = hipMemcpy(h->box_dev, hb, sizeof(hb), hipMemcpyHostToDevice);
         h->dc.box = h->box_dev;
+    }
+    if (xr) {    // the user rows' coefficients, weights and constants live in device memory (DevConsts::xr)
+        double t[kXrWords];
+        fill_extra_table(h->consts, t);
+        if (e == hipSuccess) e = alloc((void**)&h->xr_dev, sizeof(t));
+        if (e == hipSuccess) e = hipMemcpy(h->xr_dev, t, sizeof(t), hipMemcpyHostToDevice);
+        h->dc.xr = h->xr_dev;
+        h->dc.xr_n = h->consts.n_extra;
     }
     const size_t D = sizeof(double);
     {
@@ -317,6 +372,7 @@ void sddp_destroy(sddp_handle* h) {
     if (h->first_pin) (void)hipHostFree(h->first_pin);
     if (h->first_dev) (void)hipFree(h->first_dev);
     if (h->box_dev) (void)hipFree(h->box_dev);
+    if (h->xr_dev) (void)hipFree(h->xr_dev);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -742,17 +798,19 @@ int sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk
     if (consts) cc = *consts; else if (sddp_default_consts_for(model_id, &cc) != SDDP_OK) return SDDP_ERR_MODEL;
     if (!model_ops(model_id)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
     const bool bar = (cc.friction_barrier_weight > 0.0 || cc.bound_barrier_weight > 0.0) && !single_build(model_id);
-    const ModelOps* ops = model_ops(model_id, bar, false);
-    if (!ops) return fail(nullptr, SDDP_ERR_ARG, "this model has no barrier build");
+    const bool xr = cc.n_extra != 0;
+    const ModelOps* ops = model_ops(model_id, bar, false, xr);
+    if (!ops) return fail(nullptr, SDDP_ERR_ARG, "this model has no such build (barrier / user rows)");
     const Dims d = ops->dims;
     if (nk < 1 || !k || !x || !u || !p) return fail(nullptr, SDDP_ERR_ARG, "bad argument");
+    if (xr) { const char* msg = check_extra(cc, d.nx, d.nu); if (msg) return fail(nullptr, SDDP_ERR_ARG, msg); }
     DevConsts dc = make_dev_consts(cc);
     const int nz = d.nx + d.nu;
     const size_t D = sizeof(double);
     // every device buffer of the call in one table, freed on every return path
-    enum { B_BOX, B_K, B_X, B_U, B_P, B_REC, B_F, B_FF, B_H, B_G, B_L, B_N };
+    enum { B_XR, B_BOX, B_K, B_X, B_U, B_P, B_REC, B_F, B_FF, B_H, B_G, B_L, B_N };
     void* buf[B_N] = {};
-    const size_t bytes[B_N] = {bar ? 128 * D : 0, nk * sizeof(int), size_t(nk) * d.nx * D, size_t(nk) * d.nu * D, size_t(nk) * d.np * D,
+    const size_t bytes[B_N] = {xr ? kXrWords * D : 0, bar ? 128 * D : 0, nk * sizeof(int), size_t(nk) * d.nx * D, size_t(nk) * d.nu * D, size_t(nk) * d.np * D,
                                size_t(nk) * d.nrec * D, size_t(nk) * d.nx * D, size_t(nk) * d.nx * nz * D, size_t(nk) * nz * nz * D,
                                size_t(nk) * nz * D, size_t(nk) * D};
     auto release = [&]() { for (void* b : buf) if (b) (void)hipFree(b); };
@@ -764,6 +822,13 @@ int sddp_eval_knots(int model_id, const sddp_model_consts* consts, int N, int nk
         for (int i = 0; i < 64; ++i) { hb[i] = cc.lower[i]; hb[64 + i] = cc.upper[i]; }
         TRY0(hipMemcpy(buf[B_BOX], hb, sizeof(hb), hipMemcpyHostToDevice));
         dc.box = static_cast<double*>(buf[B_BOX]);
+    }
+    if (xr) {
+        double t[kXrWords];
+        fill_extra_table(cc, t);
+        TRY0(hipMemcpy(buf[B_XR], t, sizeof(t), hipMemcpyHostToDevice));
+        dc.xr = static_cast<double*>(buf[B_XR]);
+        dc.xr_n = cc.n_extra;
     }
     TRY0(hipMemcpy(buf[B_K], k, bytes[B_K], hipMemcpyHostToDevice));
     TRY0(hipMemcpy(buf[B_X], x, bytes[B_X], hipMemcpyHostToDevice));

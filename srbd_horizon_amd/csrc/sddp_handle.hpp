@@ -89,6 +89,7 @@ struct sddp_handle {
     const void* last_kernel = nullptr;   // ... and that kernel, its dynamic LDS bytes and its workgroups per CU (sddp_kernel_resources)
     int last_lds = 0, last_per_cu = 0;
     double* box_dev = nullptr;      // lower[64] | upper[64] of the bound barrier (barrier builds)
+    double* xr_dev = nullptr;       // user rows: coefficients | weights | constants (DevConsts::xr, "_x" builds)
     double* first_dev = nullptr;    // [B][nu + nx + 3] packed first knots of sddp_solve_resident_first, and its pinned host image
     double* first_pin = nullptr;
     char* up_pin = nullptr;         // pinned ring for small host->device uploads of the setters (no wait per call)

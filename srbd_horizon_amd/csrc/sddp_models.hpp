@@ -35,7 +35,43 @@ struct DevConsts {
     unsigned long long box_lm, box_um;   // ... bit j: z_j has a finite lower / upper bound
     const double* box;             // ... device array lower[64] | upper[64] (a pointer, not 128 kernel-argument words: those are
                                    //     loop-invariant scalar loads the compiler hoists and keeps live -- 3.9 KB of scratch)
+    // user-declared linear residual rows ("_x" builds, sddp.h extra_*): rows in use, and the device table
+    //   a [kXrRows][kXrStride] | weight as a state row [8] | weight as a stage row [8] | constant part of the reference [8]
+    int xr_n;
+    const double* xr;
 };
+constexpr int kXrRows = 8, kXrStride = 128, kXrWS = kXrRows * kXrStride, kXrWG = kXrWS + 8, kXrC = kXrWG + 8, kXrWords = kXrC + 8;
+
+// The user rows of one knot: cost sum_j w_j e_j^2 with e_j = a_j . z - (p_ref[j] + const_j), w_j = the row's weight where its kind is
+// active (state rows: nodes >= 1, terminal included; stage rows: nodes < N), and -- g != nullptr -- the gradient 2 w_j e_j a_j added
+// into g[NX + NU].  Compile-time indices into x / u (register arrays); the coefficients are wave-uniform loads.
+template <int NX, int NU, class XV, class UV>
+__device__ __forceinline__ double xr_eval(const DevConsts& c, XV x, UV u, bool has_u, const double* pref, bool state_on, bool stage_on,
+                                          double* g = nullptr) {
+    double L = 0.0;
+    for (int j = 0; j < c.xr_n; ++j) {
+        const double* a = c.xr + j * kXrStride;
+        const double w = (state_on ? c.xr[kXrWS + j] : 0.0) + (stage_on ? c.xr[kXrWG + j] : 0.0);
+        double e = -pref[j] - c.xr[kXrC + j];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) e = fma(a[i], x[i], e);
+        if (has_u) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) e = fma(a[NX + i], u[i], e);
+        }
+        L = fma(w * e, e, L);
+        if (g) {
+            const double t = 2.0 * w * e;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) g[i] = fma(t, a[i], g[i]);
+            if (has_u) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) g[NX + i] = fma(t, a[NX + i], g[NX + i]);
+            }
+        }
+    }
+    return L;
+}
 
 inline DevConsts make_dev_consts(const sddp_model_consts& c) {
     DevConsts d;
@@ -66,6 +102,8 @@ inline DevConsts make_dev_consts(const sddp_model_consts& c) {
     d.bar_s = c.friction_barrier_sharpness;
     d.box_w = c.bound_barrier_weight;
     d.box_s = c.bound_barrier_sharpness;
+    d.xr_n = 0;
+    d.xr = nullptr;
     d.box_lm = d.box_um = 0;
     for (int i = 0; i < 64; ++i) {
         if (c.lower[i] > -1e300) d.box_lm |= 1ull << i;
@@ -262,9 +300,12 @@ struct QSplit {
 // (reference problem, prb.py:32-68) -- NC=4: srbd37 (contact_model = 2, the launch file's), NC=8: srbd61 (contact_model = 4,
 // the default in the code, prb.py:39-41).  Two legs (number_of_legs = 2), CM = NC / 2 contact points per foot.
 // ---------------------------------------------------------------------------------------------------------
-template <int NC_, bool CS_, bool BAR_ = false, bool SO2_ = false>
+template <int NC_, bool CS_, bool BAR_ = false, bool SO2_ = false, int XR_ = 0>
 struct SrbdModel {
     static constexpr int NC = NC_;
+    static constexpr int NXR = XR_;        // user-declared linear residual rows ("_x" builds, sddp.h extra_*): 0 or kXrRows; their per-knot
+                                           // references are NXR further parameter columns behind the model's own
+    static_assert(XR_ == 0 || (XR_ == kXrRows && !BAR_ && !SO2_), "the _x builds are plain builds with kXrRows user rows");
     static constexpr bool CS = CS_;
     static constexpr bool BAR = BAR_;      // friction-cone exponential barrier on the contact forces (sddp.h), separate builds
     static constexpr bool SO2 = SO2_;      // full second-order builds (sddp_options.second_order = 2): the record also carries the
@@ -274,7 +315,7 @@ struct SrbdModel {
     static constexpr int NZ = NX + NU;
     static constexpr int CM = NC / 2;      // contact points per foot (rosparam contact_model, prb.py:39)
     // parameters in creation order (ddp.py:173-177): rdot_ref(3) w_ref(3) otg(1) (c_ref_i, cdot_switch_i) x NC, oref(4)
-    static constexpr int NP = CS ? 11 + 2 * NC : 19;
+    static constexpr int NPB = CS ? 11 + 2 * NC : 19, NP = NPB + NXR;
     static_assert((CS && (NC == 4 || NC == 8)) || (!CS && NC == 2), "srbd37 / srbd61 / srbd13");
     static_assert(!BAR_ || (CS ? 13 + 12 * NC : 13 + 3 * NC) <= 64, "the bound barrier's masks cover 64 entries of z");
     // relative-velocity penalty pairs (prb.py:166-170): q-th pair = (first contact of the leg, its i-th other contact)
@@ -485,6 +526,7 @@ struct SrbdModel {
         double L = input_cost(c, x, u, p, f, q);
         if (BAR) L += bound_cost(c, x, u);
         if (k >= 1) L += state_cost(c, x, p);
+        if (NXR) L += xr_eval<NX, NU>(c, x, u, true, p + NPB, k >= 1, true);
         // every component of x+ is formed from values read BEFORE the first store: x and xn may be the same array (in-place
         // rollout) or LDS columns the compiler cannot tell apart (then interleaved loads and stores would serialise)
         const double dt = c.dt;
@@ -515,7 +557,9 @@ struct SrbdModel {
 
     template <class XV>
     __device__ __forceinline__ static double term_cost(const DevConsts& c, XV x, const double* p) {
-        return state_cost(c, x, p);  // ddp.py:216-226: residuals only, no constraints
+        double L = state_cost(c, x, p);  // ddp.py:216-226: residuals only, no constraints
+        if (NXR) L += xr_eval<NX, NU>(c, x, x, false, p + NPB, true, false);
+        return L;
     }
 
     // compact derivative record of knot k (k == N: terminal -> gradient only)
@@ -685,10 +729,12 @@ struct SrbdModel {
                 }
             }
             if (BAR) (void)bound_cost(c, x, u, g, rec + REC_BB);   // bound barrier (off: zeros): gradient into g, GN Hessian diagonal into the record
+            if (NXR) (void)xr_eval<NX, NU>(c, x, u, true, p + NPB, k >= 1, true, g);   // user rows: their gradient
 #pragma unroll
             for (int i = 0; i < NZ; ++i) rec[REC_G + i] = g[i];
             return;                                     // (SO2 builds: the second-order factors are a pass of their own, so2_knot)
         }
+        if (NXR) (void)xr_eval<NX, NU>(c, x, x, false, p + NPB, true, false, g);       // terminal node: the state rows
 #pragma unroll
         for (int i = 0; i < NZ; ++i) rec[REC_G + i] = g[i];
     }
@@ -896,6 +942,12 @@ struct SrbdModel {
                 v += 2 * c.gq * (rec[REC_A + a] * rec[REC_A + b] + rec[REC_A + NA + a] * rec[REC_A + NA + b] +
                                  rec[REC_A + 2 * NA + a] * rec[REC_A + 2 * NA + b]);
         }
+        if (NXR) {   // user rows: 2 w_j a_j a_j^T with the weight of the node
+            for (int r = 0; r < c.xr_n; ++r) {
+                const double w = (state ? c.xr[kXrWS + r] : 0.0) + (stage ? c.xr[kXrWG + r] : 0.0);
+                v += 2 * w * c.xr[r * kXrStride + i] * c.xr[r * kXrStride + j];
+            }
+        }
         return v;
     }
     // -------------------------------------------------------------------------------------------------------------
@@ -905,16 +957,23 @@ struct SrbdModel {
     // augmented Jacobian F~ = [F ; Je] with its weight on the diagonal of V~ = blockdiag(Vxx+, Lambda), so that
     // Q = diag(D) + F~^T V~ F~ needs no special cases.  Only the wdot rows (A) and the quaternion blocks vary per knot.
     // -------------------------------------------------------------------------------------------------------------
-    static constexpr int NE = 6 + (CS ? 4 + 2 * NRV : 0);   // wdot(3) rddot(3) [rel_pos(4) rel_vel(2 per pair)]
+    static constexpr int NEB = 6 + (CS ? 4 + 2 * NRV : 0);   // wdot(3) rddot(3) [rel_pos(4) rel_vel(2 per pair)]
+    static constexpr int NE = NEB + NXR;                     // ... then the user rows (definition rows NEB .. NEB + NXR - 1)
     // Extra rows m >= NEV are constant (E_const) and their weights do not depend on the node: their contribution
     // sum_m lambda_m e_m e_m^T to Q is a constant matrix that the one-wave kernel adds instead of carrying the rows through the
     // tile products (srbd13: the three rddot rows -> product depth 20 -> 16).  NEV = NE: every row goes through the product.
     // Row order: first the NEV rows that must go through the tile products -- the variable wdot rows and, for the
     // reference model, the rel_pos rows whose weight depends on the node (state nodes only) -- then the constant rows with
     // node-independent weights (rddot, rel_vel).  erow() maps this order to the order of the definitions below.
-    static constexpr int NEV = CS ? 7 : 3;
+    // The user rows go through the tile products too (their weight depends on the node: state rows / stage rows), right behind the
+    // model's own product rows: sweep rows NEVB .. NEVB + NXR - 1.
+    static constexpr int NEVB = CS ? 7 : 3, NEV = NEVB + NXR;
     static constexpr bool CONST_ROWS_STATE_WEIGHTED = false;
     __device__ __forceinline__ static int erow(int m) {
+        if (NXR) {
+            if (m >= NEVB && m < NEV) return NEB + (m - NEVB);
+            if (m >= NEV) m -= NXR;
+        }
         if (!CS) return m;                       // wdot(0-2) rddot(3-5)
         if (m < 3) return m;                     // wdot
         if (m < 7) return m + 3;                 // rel_pos   (definition rows 6..9)
@@ -926,6 +985,7 @@ struct SrbdModel {
     // constant entry of extra row m w.r.t. z_j (one-time table fill; variable wdot rows are 0 here)
     __device__ static double E_const(const DevConsts& c, int mrow, int j) {
         const int m = erow(mrow);
+        if (NXR && m >= NEB) return (c.xr && m - NEB < c.xr_n) ? c.xr[(m - NEB) * kXrStride + j] : 0.0;   // user rows
         int cls, ci, ax;
         decode(j, cls, ci, ax);
         if (m < 3) return 0.0;
@@ -942,10 +1002,12 @@ struct SrbdModel {
     }
     __device__ static double lam_state(const DevConsts& c, int mrow) {
         const int m = erow(mrow);
+        if (NXR && m >= NEB) return (c.xr && m - NEB < c.xr_n) ? 2 * c.xr[kXrWS + m - NEB] : 0.0;
         return (CS && m >= 6 && m < 10) ? 2 * c.w_rel : 0.0;
     }
     __device__ static double lam_stage(const DevConsts& c, int mrow) {
         const int m = erow(mrow);
+        if (NXR && m >= NEB) return (c.xr && m - NEB < c.xr_n) ? 2 * c.xr[kXrWG + m - NEB] : 0.0;
         if (m < 6) return 2 * c.gq;
         return (CS && m >= 10) ? 2 * c.w_rv : 0.0;
     }
@@ -1257,12 +1319,15 @@ struct SrbdModel {
 // LIP (prb.py:248-441): x = r | c0..3 | rdot | cdot0..3 (30), u = z | cddot0..3 (15), p = rdot_ref | (c_ref_i, sw_i)x4.
 // Linear dynamics + quadratic cost: F and H are constant in (x,u); the record is the gradient only.
 // ---------------------------------------------------------------------------------------------------------
+template <int XR_ = 0>
 struct LipModel {
     static constexpr int NC = 4;
+    static constexpr int NXR = XR_;        // user-declared linear residual rows (see SrbdModel)
+    static_assert(XR_ == 0 || XR_ == kXrRows, "0 or kXrRows user rows");
     static constexpr bool BAR = false;
     template <class QM> __device__ __forceinline__ static void add_barrier(const double*, QM, int, int, double = 0.0) {}
     template <class QM> __device__ __forceinline__ static void add_const_rows(const DevConsts&, QM, int, int) {}   // (one Q block per thread: unused)
-    static constexpr int NX = 30, NU = 15, NZ = 45, NP = 11;
+    static constexpr int NX = 30, NU = 15, NZ = 45, NPB = 11, NP = NPB + NXR;
     static constexpr int XR = 0, XC = 3, XRD = 15, XCD = 18;
     static constexpr int REC_G = 0, NREC = NZ, NSO2T = 0, NSO2L = 0;
     static constexpr bool SO2 = false;
@@ -1314,6 +1379,7 @@ struct LipModel {
             L += c.w_rv * (ex * ex + ey * ey);
         }
         if (k >= 1) L += state_cost(c, x, p);
+        if (NXR) L += xr_eval<NX, NU>(c, x, u, true, p + NPB, k >= 1, true);
         const double dt = c.dt;
         double xp[NX];                                                            // read everything before the first store
 #pragma unroll
@@ -1329,7 +1395,9 @@ struct LipModel {
 
     template <class XV>
     __device__ __forceinline__ static double term_cost(const DevConsts& c, XV x, const double* p) {
-        return state_cost(c, x, p);
+        double L = state_cost(c, x, p);
+        if (NXR) L += xr_eval<NX, NU>(c, x, x, false, p + NPB, true, false);
+        return L;
     }
 
     __device__ __forceinline__ static void derivs(const DevConsts& c, const double* x, const double* u, const double* p,
@@ -1386,6 +1454,7 @@ struct LipModel {
                 g[XCD + 3 * b + 1] += sr * ey; g[XCD + 3 * b + 4] -= sr * ey;
             }
         }
+        if (NXR) (void)xr_eval<NX, NU>(c, x, u, k < N, p + NPB, k >= 1, k < N, g);     // user rows: their gradient
 #pragma unroll
         for (int i = 0; i < NZ; ++i) rec[REC_G + i] = g[i];
     }
@@ -1457,15 +1526,26 @@ struct LipModel {
         } else if (cli == V_CDD && clj == V_CDD) {
             if (stage && ci == cj) v = 2 * c.gq;
         }
+        if (NXR) {
+            for (int r = 0; r < c.xr_n; ++r) {
+                const double w = (state ? c.xr[kXrWS + r] : 0.0) + (stage ? c.xr[kXrWG + r] : 0.0);
+                v += 2 * w * c.xr[r * kXrStride + i] * c.xr[r * kXrStride + j];
+            }
+        }
         return v;
     }
     // ---- branch-free expansion hooks (see SrbdModel): everything is constant, all couplings are extra rows
-    static constexpr int NE = 16;   // rxy(2) zmp(3) rddot(3) rel_pos(4) rel_vel(4)
+    static constexpr int NEB = 16;  // rxy(2) zmp(3) rddot(3) rel_pos(4) rel_vel(4)
+    static constexpr int NE = NEB + NXR;   // ... then the user rows
     // product rows first: rxy(2) and rel_pos(4) carry state-node weights; then zmp(3) rddot(3) rel_vel(4): constant rows with
     // node-independent weights, which enter Q as a constant matrix
-    static constexpr int NEV = 6;
+    static constexpr int NEVB = 6, NEV = NEVB + NXR;     // the user rows go through the products too (node-dependent weights)
     static constexpr bool CONST_ROWS_STATE_WEIGHTED = false;
     __device__ __forceinline__ static int erow(int m) {
+        if (NXR) {
+            if (m >= NEVB && m < NEV) return NEB + (m - NEVB);
+            if (m >= NEV) m -= NXR;
+        }
         if (m < 2) return m;                     // rxy
         if (m < 6) return m + 6;                 // rel_pos   (definition rows 8..11)
         if (m < 12) return m - 4;                // zmp, rddot (definition rows 2..7)
@@ -1473,6 +1553,7 @@ struct LipModel {
     }
     __device__ static double E_const(const DevConsts& c, int mrow, int j) {
         const int m = erow(mrow);
+        if (NXR && m >= NEB) return (c.xr && m - NEB < c.xr_n) ? c.xr[(m - NEB) * kXrStride + j] : 0.0;   // user rows
         int cls, ci, ax;
         decode(j, cls, ci, ax);
         if (m < 2) { if (ax != m) return 0.0; return cls == V_R ? 1.0 : (cls == V_C ? -0.25 : 0.0); }           // prb.py:391
@@ -1489,10 +1570,12 @@ struct LipModel {
     }
     __device__ static double lam_state(const DevConsts& c, int mrow) {
         const int m = erow(mrow);
+        if (NXR && m >= NEB) return (c.xr && m - NEB < c.xr_n) ? 2 * c.xr[kXrWS + m - NEB] : 0.0;
         return m < 2 ? 2 * c.w_rxy : ((m >= 8 && m < 12) ? 2 * c.w_rel : 0.0);
     }
     __device__ static double lam_stage(const DevConsts& c, int mrow) {
         const int m = erow(mrow);
+        if (NXR && m >= NEB) return (c.xr && m - NEB < c.xr_n) ? 2 * c.xr[kXrWG + m - NEB] : 0.0;
         if (m < 2) return 0.0;
         if (m < 5) return 2 * c.w_zmp;
         if (m < 8) return 2 * c.gq;
@@ -1564,6 +1647,9 @@ using Srbd37S = SrbdModel<4, true, false, true>;
 using Srbd13BS = SrbdModel<2, false, true, true>;    // barrier + full second order
 using Srbd37BS = SrbdModel<4, true, true, true>;
 using Srbd61 = SrbdModel<8, true>;                  // contact_model = 4 (prb.py:39-41): default build only
-using Lip30 = LipModel;
+using Lip30 = LipModel<>;
+using Srbd13X = SrbdModel<2, false, false, false, kXrRows>;   // with user-declared linear residual rows (sddp_model_consts.n_extra > 0)
+using Srbd37X = SrbdModel<4, true, false, false, kXrRows>;
+using Lip30X = LipModel<kXrRows>;
 
 }  // namespace sddp

@@ -20,7 +20,7 @@ from typing import Dict
 import numpy as np
 
 from .engine import DdpEngine
-from .problem import Problem
+from .problem import LinearTerm, Problem
 
 # option keys the reference forwards to pyddp.DdpSolverOptions (ddp.py:16-35) + engine extras
 _REFERENCE_KEYS = ("max_iters", "alpha_0", "alpha_converge_threshold", "line_search_decrease_factor", "beta",
@@ -92,8 +92,20 @@ class DDPSolver:
         self.ddp_solver = DdpEngine(prb.model, prb.nodes - 1, 1, opts=self.opts, consts=consts)
         if (self.ddp_solver.nx, self.ddp_solver.nu) != (self.state_size, self.input_size):
             raise ValueError("problem variables do not match the registered model's dimensions")
-        if self.ddp_solver.np_ != sum(p.getDim() for p in self.param_var.values()):
-            raise ValueError("problem parameters do not match the registered model's parameter vector")
+        from . import _lib
+        self._np_model = _lib.model_dims(prb.model)[2]
+        own, user = 0, []
+        for p in self.param_var.values():          # the model's own parameters come first (creation order); the rest are the user's
+            if own < self._np_model:
+                own += p.getDim()
+            else:
+                user.append(p)
+        refs = {id(r[0]) for r in self._extra_refs if r is not None}
+        if own != self._np_model or any(id(p) not in refs for p in user):
+            raise ValueError("problem parameters do not match the registered model's parameter vector (further parameters must be "
+                             "references of declared LinearTerm residuals)")
+        if self.ddp_solver.np_ != self._np_model + (8 if self._extra_refs else 0):
+            raise ValueError("engine / problem parameter widths disagree")
         self.var_solution = None
         self._have_x0 = self._have_x = self._have_u = False
 
@@ -125,7 +137,7 @@ class DDPSolver:
         if not self._have_x:
             self.ddp_solver.set_x_warmstart(np.repeat(self._x0[:, None, :], self.prb.nodes, axis=1))
             self._have_x = True
-        params = self.prb.parameter_matrix()[None]                          # ddp.py:98-99, vectorised
+        params = self._parameter_matrix()[None]                             # ddp.py:98-99, vectorised
         x, u = self.ddp_solver.solve(params)                                # ddp.py:101
         x, u = np.ascontiguousarray(x[0].T), np.ascontiguousarray(u[0].T)   # reference layout [dim, nodes]
         self.var_solution = self._createVarSolDict(x, u)
@@ -144,7 +156,7 @@ class DDPSolver:
         result as ``setInitialState(x0)`` + shifted ``set_*_warmstart`` + ``solve()`` (tests/test_gpu_api.py)."""
         x0 = np.asarray(x0, dtype=float).reshape(1, self.state_size)
         self._x0 = x0.copy()
-        pm = self.prb.parameter_matrix()
+        pm = self._parameter_matrix()
         if not getattr(self, "_resident", False):
             self.setInitialState(x0)
             if not self._have_u:
@@ -212,9 +224,14 @@ class DDPSolver:
         cost = self.fun_container.getCost()
         if not cost and not self.fun_container.getCnstr():
             return consts                                       # a problem without declarations: the model's built-in defaults
-        unknown = [n for n in cost if n not in table["cost"]]
+        self._extra_refs = []
+        linear = {n: fn for n, fn in cost.items() if isinstance(fn.term, LinearTerm)}
+        if linear:
+            consts["extra_rows"] = self._linear_rows(linear, ranges)
+        unknown = [n for n in cost if n not in table["cost"] and n not in linear]
         if unknown:
-            raise NotImplementedError(f"model {prb.model} has no analytic term for residual(s) {unknown}")
+            raise NotImplementedError(f"model {prb.model} has no analytic term for residual(s) {unknown}: declare a linear residual "
+                                      "as problem.LinearTerm, anything else needs a model term")
         gains = {}
         for name, (ckey, kind) in table["cost"].items():
             fn = cost.get(name)
@@ -254,6 +271,47 @@ class DDPSolver:
         if bad:
             raise NotImplementedError(f"model {prb.model} has no barrier for inequality constraint(s) {bad}")
         return consts
+
+    def _linear_rows(self, linear, ranges):
+        """User-declared linear residuals -> the extra rows of the model's "_x" build (include/sddp.h extra_*): coefficient vector
+        over z = [x u] in creation order, weight = the gain, kind from the node range; self._extra_refs[j] = (Parameter, row) whose
+        per-node values fill reference column j of the widened parameter vector."""
+        off, o = {}, 0
+        for v in list(self.state_var) + list(self.input_var):
+            off[v] = o
+            o += v.getDim()
+        nz = self.state_size + self.input_size
+        rows = []
+        for name, fn in linear.items():
+            t = fn.term
+            kind = "state" if fn.getNodes() == ranges["state"] else ("stage" if fn.getNodes() == ranges["stage"] else None)
+            if kind is None:
+                raise NotImplementedError(f"residual {name!r}: a linear residual lives on nodes 1..N (state term) or 0..N-1 (stage term)")
+            for r in range(t.dim):
+                a = np.zeros(nz)
+                for v, A in t.coeffs.items():
+                    if v not in off:
+                        raise ValueError(f"residual {name!r}: {v} is not a state or input variable of this problem")
+                    a[off[v]:off[v] + v.getDim()] += A[r]
+                if kind == "state" and np.any(a[self.state_size:] != 0.0):
+                    raise NotImplementedError(f"residual {name!r}: a term on nodes 1..N is active at the terminal node and cannot touch the inputs")
+                rows.append(dict(a=a, w=t.gain, kind=kind, const=float(t.const[r])))
+                self._extra_refs.append(None if t.ref is None else (t.ref, r))
+        if len(rows) > 8:
+            raise NotImplementedError(f"{len(rows)} linear residual rows declared; the analytic models carry at most 8")
+        return rows
+
+    def _parameter_matrix(self):
+        """[N+1, np]: the model's own parameters (ddp.py:165-177, creation order); with user rows, 8 more columns: their references"""
+        P = self.prb.parameter_matrix()
+        if not self._extra_refs:
+            return P
+        out = np.zeros((P.shape[0], self._np_model + 8))
+        out[:, :self._np_model] = P[:, :self._np_model]
+        for j, ref in enumerate(self._extra_refs):
+            if ref is not None:
+                out[:, self._np_model + j] = ref[0].values[ref[1], :]
+        return out
 
     def _createVarSolDict(self, x, u):
         """ddp.py:125-151: walk the variables in creation order; states first, then inputs."""

@@ -25,6 +25,9 @@ class DdpEngine:
         _lib.check(self.lib.sddp_create(C.byref(h), _lib.MODEL_IDS[model], self.N, self.B,
                                         C.byref(self.opts), C.byref(self.consts)))
         self.h = h
+        npar = C.c_int()                     # a handle with user rows (consts extra_rows) has MAX_EXTRA more parameter columns
+        self._chk(self.lib.sddp_handle_dims(h, None, None, C.byref(npar)))
+        self.np_ = npar.value
         self._keep = []
 
     # ---- lifetime ------------------------------------------------------------------------------------------------
@@ -306,8 +309,10 @@ def eval_knots(model: str, N: int, k, x, u, p, consts: dict | None = None):
     nk = k.shape[0]
     x = np.ascontiguousarray(x, dtype=np.float64).reshape(nk, nx)
     u = np.ascontiguousarray(u, dtype=np.float64).reshape(nk, nu)
-    p = np.ascontiguousarray(p, dtype=np.float64).reshape(nk, npar)
     cst = _lib.default_consts(model, **(consts or {}))
+    if cst.n_extra:
+        npar += _lib.MAX_EXTRA               # the user rows' reference columns
+    p = np.ascontiguousarray(p, dtype=np.float64).reshape(nk, npar)
     f = np.empty((nk, nx)); F = np.empty((nk, nx, nz)); H = np.empty((nk, nz, nz)); g = np.empty((nk, nz)); L = np.empty(nk)
     _lib.check(lib.sddp_eval_knots(_lib.MODEL_IDS[model], C.byref(cst), int(N), nk, _lib.ptr(k), _lib.ptr(x), _lib.ptr(u),
                                    _lib.ptr(p), _lib.ptr(f), _lib.ptr(F), _lib.ptr(H), _lib.ptr(g), _lib.ptr(L)))

@@ -166,6 +166,34 @@ class Term:
         return f"Term({self.key!r}, {self.consts_key}={self.gain})"
 
 
+class LinearTerm(Term):
+    """A user-declared LINEAR residual -- what ``createResidual(name, sqrt(gain) * (A_1 @ v_1 + A_2 @ v_2 + ... - ref))`` is in the
+    reference, where ``get_L`` / ``get_L_term`` sum whatever residual the container holds (ddp.py:183-196, :216-226).  The analytic
+    models take up to 8 such rows on top of prb.py's own terms (include/sddp.h ``extra_*``).
+
+    coeffs: {Variable: matrix [dim, variable dim]} over state and input variables; gain: the weight under the square root;
+    ref: a Parameter of dimension dim created for this term (its per-node values are the reference), or None; const: constant part
+    of the reference (scalar or [dim]).  Node range: 1..N (a state term like prb.py's tracking terms; states only) or 0..N-1 (a
+    stage term like min_qddot)."""
+
+    def __init__(self, coeffs: dict, gain: float, ref=None, const=0.0):
+        mats = {v: np.atleast_2d(np.asarray(A, dtype=float)) for v, A in coeffs.items()}
+        dims = {A.shape[0] for A in mats.values()}
+        if len(dims) != 1:
+            raise ValueError("LinearTerm: every coefficient matrix needs the same number of rows")
+        dim = dims.pop()
+        for v, A in mats.items():
+            if not isinstance(v, Variable) or A.shape[1] != v.getDim():
+                raise ValueError("LinearTerm: coeffs maps state / input Variables to [dim, variable dim] matrices")
+        if ref is not None and ref.getDim() != dim:
+            raise ValueError("LinearTerm: the reference parameter needs one entry per row")
+        if not (float(gain) >= 0.0):
+            raise ValueError("LinearTerm: gain must be >= 0")
+        super().__init__("linear", None, float(gain), dim)
+        self.coeffs, self.ref = mats, ref
+        self.const = np.broadcast_to(np.asarray(const, dtype=float).reshape(-1), (dim,)).copy()
+
+
 class Function:
     """A cost term or constraint of the problem (Horizon ``Function`` / ``Constraint`` as ddp.py:42-48, :184-196 use them)."""
 

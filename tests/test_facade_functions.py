@@ -133,3 +133,44 @@ def test_four_point_feet_is_the_srbd37_layout_without_relative_velocity_constrai
     for bad in (dict(number_of_legs=4, contact_model=2), dict(number_of_legs=1, contact_model=4), dict(number_of_legs=2, contact_model=3)):
         with pytest.raises(ValueError):
             SRBDProblem().createSRBDProblem(NS, 1.0, params=bad)
+
+
+def test_linear_terms_become_extra_rows_of_the_model():
+    """A user adds a tracking term to prb.py's problem (ddp.py:183-196 would just sum it): problem.LinearTerm -> the extra rows
+    of the model's "_x" build -- coefficient vector over z = [x u] in creation order, kind from the node range, the reference
+    parameter mapped to the widened parameter vector.  What the analytic models cannot express still raises."""
+    from srbd_horizon_amd.problem import LinearTerm
+    pb = SRBDProblem(); prb = pb.createSRBDProblem(NS, 1.0)
+    c0_ref = prb.createParameter("c0_xy_ref", 2)
+    c0_ref.assign(np.array([0.1, 0.2]))
+    c0_ref.assign(np.array([0.3, 0.4]), nodes=[NS])
+    prb.createResidual("c0_xy_tracking", LinearTerm({pb.c[0]: [[1, 0, 0], [0, 1, 0]]}, gain=250.0, ref=c0_ref), nodes=range(1, NS + 1))
+    prb.createResidual("f_balance", LinearTerm({pb.f[0]: [[0, 0, 1]], pb.f[2]: [[0, 0, -1]]}, gain=4.0, const=0.5), nodes=range(0, NS))
+    a = _adapter(prb)
+    a.state_var = prb.getState().getVars(); a.input_var = prb.getInput().getVars()
+    a.state_size, a.input_size = 37, 24
+    c = a._model_consts_from_functions()
+    rows = c["extra_rows"]
+    assert [r["kind"] for r in rows] == ["state", "state", "stage"] and [r["w"] for r in rows] == [250.0, 250.0, 4.0]
+    assert rows[0]["a"][7] == 1.0 and rows[1]["a"][8] == 1.0 and np.count_nonzero(rows[0]["a"]) == 1          # c0 = x[7:10]
+    assert rows[2]["a"][37 + 5] == 1.0 and rows[2]["a"][37 + 17] == -1.0 and rows[2]["const"] == 0.5          # f_i = u[6 i + 3 : 6 i + 6]
+    a._np_model = 19
+    P = a._parameter_matrix()
+    assert P.shape == (NS + 1, 27)
+    np.testing.assert_array_equal(P[:, :19], prb.parameter_matrix()[:, :19])
+    np.testing.assert_array_equal(P[0, 19:22], [0.1, 0.2, 0.0]); np.testing.assert_array_equal(P[NS, 19:21], [0.3, 0.4])
+    # limits: node ranges, inputs in a state term, more than 8 rows, non-linear anything
+    prb.createResidual("bad_nodes", LinearTerm({pb.c[0]: [[1, 0, 0]]}, gain=1.0), nodes=range(2, NS))
+    with pytest.raises(NotImplementedError):
+        a._model_consts_from_functions()
+    prb.removeCostFunction("bad_nodes")
+    prb.createResidual("bad_inputs", LinearTerm({pb.f[0]: [[1, 0, 0]]}, gain=1.0), nodes=range(1, NS + 1))
+    with pytest.raises(NotImplementedError):
+        a._model_consts_from_functions()
+    prb.removeCostFunction("bad_inputs")
+    prb.createResidual("too_many", LinearTerm({pb.c[1]: np.eye(3), pb.c[2]: np.eye(3)}, gain=1.0), nodes=range(1, NS + 1))
+    prb.createResidual("too_many2", LinearTerm({pb.cdot[1]: np.eye(3)}, gain=1.0), nodes=range(1, NS + 1))
+    with pytest.raises(NotImplementedError):
+        a._model_consts_from_functions()
+    with pytest.raises(ValueError):
+        LinearTerm({pb.c[0]: [[1, 0]]}, gain=1.0)
