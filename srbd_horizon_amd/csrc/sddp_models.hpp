@@ -1491,8 +1491,15 @@ struct LipModel {
         int ci, cli, ai, cj, clj, aj;
         decode(i, cli, ci, ai);
         decode(j, clj, cj, aj);
-        if (ai != aj) return 0.0;
         const bool state = k >= 1, stage = k < N;
+        double vx = 0.0;
+        if (NXR) {   // user rows: 2 w_j a_j a_j^T with the weight of the node
+            for (int r = 0; r < c.xr_n; ++r) {
+                const double w = (state ? c.xr[kXrWS + r] : 0.0) + (stage ? c.xr[kXrWG + r] : 0.0);
+                vx += 2 * w * c.xr[r * kXrStride + i] * c.xr[r * kXrStride + j];
+            }
+        }
+        if (ai != aj) return vx;
         if (cli > clj) { int t = cli; cli = clj; clj = t; t = ci; ci = cj; cj = t; }
         const double e4 = 2 * c.gq * c.eta2 * c.eta2;
         double v = 0.0;
@@ -1526,13 +1533,7 @@ struct LipModel {
         } else if (cli == V_CDD && clj == V_CDD) {
             if (stage && ci == cj) v = 2 * c.gq;
         }
-        if (NXR) {
-            for (int r = 0; r < c.xr_n; ++r) {
-                const double w = (state ? c.xr[kXrWS + r] : 0.0) + (stage ? c.xr[kXrWG + r] : 0.0);
-                v += 2 * w * c.xr[r * kXrStride + i] * c.xr[r * kXrStride + j];
-            }
-        }
-        return v;
+        return v + vx;
     }
     // ---- branch-free expansion hooks (see SrbdModel): everything is constant, all couplings are extra rows
     static constexpr int NEB = 16;  // rxy(2) zmp(3) rddot(3) rel_pos(4) rel_vel(4)

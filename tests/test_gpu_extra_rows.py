@@ -93,11 +93,12 @@ def test_one_sweep_and_one_pass_with_extra_rows():
     kff, K, scal = eng.backward(P, mu=0.0)
     xs = batch["xs"][0].copy(); xs[0] = batch["x0"][0]
     d = oddp.defects(m, xs, batch["us"][0], P[0])
-    bw = oddp.backward_pass(m, xs, batch["us"][0], P[0], d, 0.0)
-    np.testing.assert_allclose(kff[0], bw.kff, rtol=1e-7, atol=1e-9)
-    np.testing.assert_allclose(K[0], bw.K, rtol=1e-7, atol=1e-8)
-    xg, ug, Jg = eng.forward(P, 0.5)
-    xo, uo, Jo = oddp.forward_pass(m, batch["x0"][0], xs, batch["us"][0], P[0], d, bw.K, bw.kff, 0.5)
+    ok, Ko, ko = oddp.backward_pass(m, xs, batch["us"][0], P[0], d, 0.0)[:3]
+    assert ok
+    np.testing.assert_allclose(kff[0], ko, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(K[0], Ko, rtol=1e-7, atol=1e-8)
+    xg, ug, Jg = eng.forward(P, 0.125)                      # (0.5 blows up from this cold start, in the oracle too)
+    xo, uo, Jo = oddp.forward_pass(m, batch["x0"][0], xs, batch["us"][0], P[0], d, Ko, ko, 0.125)
     assert np.max(np.abs(xg[0] - xo)) <= 1e-9 and abs(Jg[0] - Jo) <= 1e-9 * abs(Jo)
 
 
