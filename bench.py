@@ -17,11 +17,16 @@ all-gather of the solution records when N > 1), on ONE stream.
 
 Why a queue: a batch ends with its slowest instance (up to 100 DDP iterations; the mean is 16) and 1024 instances do not fill
 2048 wavefront slots, so one launch per batch leaves most SIMD time idle.  A launch of a queue still ends with its slowest
-instance, so the order matters.  `value` is measured with `queue_order = 2`: a pre-pass of the launch evaluates every
-instance's initial cost and the queue starts the costliest warm starts first -- no history, no foreknowledge.  Reported beside
-it: plain index order, and `replay_history_order_solves_per_s` = longest-previous-solve-first on a handle that HAS solved the
-same instances once before (exact foreknowledge: the upper bound a fleet of recurring robots approaches; round 2's headline),
-and the strictly sequential one-batch-per-launch figure as `one_batch_in_flight_*`.  Weak scaling.
+instance, so the order matters.  `value` is measured with `queue_order = 3`: every instance carries a CLASS label computed from
+its schedule before it is solved (which feet stand at node 0, nodes to the first contact switch, whether a forward / lateral
+velocity is commanded: srbd_horizon_amd.workload.srbd13_schedule_classes), the handle keeps the mean iteration count of every class
+over the instances it has solved so far -- at the start of the first timed region: the warm-up steps, other instances -- and the
+queue starts the classes with the longest history first, the initial cost (a pre-pass of the launch) breaking ties.  No instance
+of a timed region has been solved before, nothing of its solution is known.  Reported beside it: `initial_cost_order_solves_per_s`
+(queue_order 2: the pre-pass alone, no history at all: rounds 3-4's headline), plain index order, and
+`replay_history_order_solves_per_s` = longest-previous-solve-first on a handle that HAS solved the same instances once before
+(exact foreknowledge: the upper bound a fleet of recurring robots approaches; round 2's headline), and the strictly sequential
+one-batch-per-launch figure as `one_batch_in_flight_*`.  Weak scaling.
 
 Rank 0 prints ONE JSON line; `roofline` and `cpu_baseline` are defined in DESIGN.md ("Measurement").
 """
@@ -213,7 +218,9 @@ def drain_profile(slot_t):
             "launch_ms_by_slot_clock": float(total / 1e5), "slots": int(len(ends))}
 
 
-ORDER_NAMES = {0: "index", 1: "longest previous solve first (history of this handle)", 2: "largest initial cost first (pre-pass of the launch, no history)"}
+ORDER_NAMES = {0: "index", 1: "longest previous solve first (history of this handle)", 2: "largest initial cost first (pre-pass of the launch, no history)",
+               3: "longest class history first: mean iterations of the instance's schedule class (stance at node 0, nodes to the first contact "
+                  "switch, commanded velocity pattern) over the OTHER instances this handle has solved -- here the warm-up steps; initial cost breaks ties"}
 
 
 def main():
@@ -226,8 +233,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the single-instance extras")
     ap.add_argument("--queue-depth", type=int, default=64, help="steps (batches) one engine handle holds = most steps per launch")
     ap.add_argument("--waves-per-simd", type=int, default=2, help="kernel build: 1 = one wavefront per SIMD, 2 = two")
-    ap.add_argument("--queue-order", type=int, default=2, help="sddp_options.queue_order: 2 largest initial cost first (no history), "
-                                                              "0 index order, 1 longest previous solve first (needs history)")
+    ap.add_argument("--queue-order", type=int, default=3, help="sddp_options.queue_order: 3 longest class history first (classes = schedule "
+                                                              "features known before the solve; history = the warm-up steps), 2 largest initial "
+                                                              "cost first (no history), 0 index order, 1 longest previous solve first (needs history)")
     ap.add_argument("--launches-per-region", type=int, default=0,
                     help="split a timed region's steps over this many launches (0 = default = 1; 2: the all-gather of launch k is on "
                          "the wire while launch k + 1 solves, at the price of two drains)")
@@ -277,7 +285,10 @@ def main():
     def load_blocks(blocks, x0_draw=0):
         seeds = np.concatenate([b * B + np.arange(B) for b in blocks])
         h = workload.make_srbd13_batch(N, seeds, x0_draw=x0_draw)
-        return {k: torch.from_numpy(h[k]).to(dev).reshape((len(blocks), B) + h[k].shape[1:]) for k in ("x0", "xs", "us", "params")}
+        d = {k: torch.from_numpy(h[k]).to(dev).reshape((len(blocks), B) + h[k].shape[1:]) for k in ("x0", "xs", "us", "params")}
+        lab, ncls = workload.srbd13_schedule_classes(h["params"])       # what kind of problem each instance is (queue order 3)
+        d["classes"], d["n_classes"] = torch.from_numpy(lab).to(dev).reshape(len(blocks), B), ncls
+        return d
 
     run_blocks = [[seed_block(rank, world, steps, warmup, "timed", i, run=r) for i in range(steps)] for r in range(RUNS)]
     timed_blocks = run_blocks[0]
@@ -311,7 +322,7 @@ def main():
         for i in range(n_steps):
             if fl.full:
                 launch(fl, count)
-            fl.submit(d["x0"][i], d["xs"][i], d["us"][i], d["params"][i])    # one step: one batch of new instances enters the queue
+            fl.submit(d["x0"][i], d["xs"][i], d["us"][i], d["params"][i], d["classes"][i], d["n_classes"])    # one step: one batch of new instances enters the queue
         launch(fl, count)
         fl.wait()                                              # every collective of the region has completed
 
@@ -427,7 +438,8 @@ def main():
         run_steps(f_o, d_sim, n_x)
         out["history_order_similar_problems_solves_per_s"] = B * n_x / timed(f_o, d_t, n_x)
         del f_o, e_o, d_sim
-        for order, key in ((0, "index_order_solves_per_s"), (1, "replay_history_order_solves_per_s"), (2, "initial_cost_order_solves_per_s")):
+        for order, key in ((0, "index_order_solves_per_s"), (1, "replay_history_order_solves_per_s"), (2, "initial_cost_order_solves_per_s"),
+                           (3, "class_history_order_solves_per_s")):
             if order == args.queue_order:
                 continue
             e_o, f_o = make_queue(order)

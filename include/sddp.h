@@ -71,6 +71,12 @@ typedef struct sddp_options {
                                            2: largest INITIAL COST first -- a pre-pass of the same launch evaluates the total cost of
                                               every instance's warm start and the queue is sorted by it (descending): needs no history,
                                               the order for cold queues (instances never seen before);
+                                           3: longest CLASS HISTORY first -- the caller labels every instance with the class of
+                                              problem it is (sddp_set_instance_classes: gait phase, command, ...; no knowledge of
+                                              the solution); the key is the mean iteration count the earlier solves of that class
+                                              took on this handle, the initial cost of order 2 breaking ties; classes not seen yet
+                                              (and unlabelled instances) start first.  New instances of known kinds: what a fleet
+                                              server sees.  (v9)
                                            0: index order. */
     int    max_slots;                   /* 0 (default): every workgroup the device can keep resident is a queue slot.  > 0: at most
                                            this many (diagnostics and tests: a queue on few instances); reported by sddp_queue_info */
@@ -200,6 +206,14 @@ int  sddp_solve_range_device(sddp_handle* h, const double* d_params, int first, 
  * sddp_record_words: doubles per record.  (v9) */
 int  sddp_record_words(sddp_handle* h, int mode, int* words);
 int  sddp_pack_records_device(sddp_handle* h, int first, int count, int mode, double* d_out);
+/* Class labels for queue_order = 3: classes[b] in [0, n_classes) (or -1: unlabelled) says what kind of problem instance b is --
+ * anything the caller knows BEFORE the solve that correlates with its length.  The handle keeps, per class, the iterations and the
+ * number of solves of every labelled instance it has solved (under any queue order) and orders a queued launch by the class
+ * means.  Host pointer [B] (synchronous) / device pointer to `count` labels for the instances [first, first + count) (asynchronous
+ * on the handle's stream: the fleet-queue path).  n_classes is fixed by the first call.  sddp_class_history reads one class. (v9) */
+int  sddp_set_instance_classes(sddp_handle* h, const int* classes /*[B]*/, int n_classes);
+int  sddp_set_instance_classes_range_device(sddp_handle* h, int first, int count, const int* d_classes, int n_classes);
+int  sddp_class_history(sddp_handle* h, int cls, double* mean_iters, long long* solves);
 /* slots: resident workgroups the work buffers exist for; grid and queue length (0: no queue) of the last solve launch */
 int  sddp_queue_info(sddp_handle* h, int* slots, int* last_grid, int* last_queued);
 /* which kernel a handle runs: wavefronts per instance (1: solve_kernel, 4: solve_kernel_mw), the build the LAST solve launch used

@@ -91,6 +91,9 @@ SYMBOLS = {
     "sddp_solve_range_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "sddp_record_words": (C.c_int, [_vp, C.c_int, _P(C.c_int)]),
     "sddp_pack_records_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "sddp_set_instance_classes": (C.c_int, [_vp, _vp, C.c_int]),
+    "sddp_set_instance_classes_range_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int]),
+    "sddp_class_history": (C.c_int, [_vp, C.c_int, _P(C.c_double), _P(C.c_longlong)]),
     "sddp_queue_info": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "sddp_fetch": (C.c_int, [_vp, _vp, _vp, _vp]),
     "sddp_synchronize": (C.c_int, [_vp]),

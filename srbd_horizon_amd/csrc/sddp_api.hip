@@ -45,6 +45,19 @@ int launch_queue_order(sddp_handle* h, int first, int count) {
     return SDDP_OK;
 }
 
+int launch_class_keys(sddp_handle* h, int count) {
+    hipLaunchKernelGGL(class_key_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, count, h->order_in, h->cls, h->n_cls, h->cls_stat,
+                       h->qkey);
+    HIP_TRY(h, hipGetLastError());
+    return SDDP_OK;
+}
+int launch_class_update(sddp_handle* h, int first, int count) {
+    hipLaunchKernelGGL(class_update_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, first, count, h->cls, h->n_cls, h->stats,
+                       h->cls_stat);
+    HIP_TRY(h, hipGetLastError());
+    return SDDP_OK;
+}
+
 int alloc_cold_queue(sddp_handle* h) {
     if (h->sort_tmp) return SDDP_OK;               // the last pointer of the group: set only when all of it exists
     double *k1 = nullptr, *k2 = nullptr;
@@ -164,7 +177,7 @@ int validate_options(sddp_handle* h, const sddp_options& o) {
         std::log(o.alpha_converge_threshold / o.alpha_0) / std::log(o.line_search_decrease_factor) > 4096.0)
         return fail(h, SDDP_ERR_ARG, "line search ladder longer than 4096 step lengths (line_search_decrease_factor too close to 1 "
                                      "or alpha_converge_threshold too small)");
-    if (o.queue_order < 0 || o.queue_order > 2) return fail(h, SDDP_ERR_ARG, "queue_order must be 0, 1 or 2");
+    if (o.queue_order < 0 || o.queue_order > 3) return fail(h, SDDP_ERR_ARG, "queue_order must be 0, 1, 2 or 3");
     if (o.max_slots < 0) return fail(h, SDDP_ERR_ARG, "max_slots must be >= 0");
     if (o.second_order < 0 || o.second_order > 2) return fail(h, SDDP_ERR_ARG, "second_order must be 0, 1 or 2");
     return SDDP_OK;
@@ -350,7 +363,7 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
         sddp_destroy(h);
         return SDDP_ERR_HIP;
     }
-    if (h->opts.queue_order == 2) {   // cold-queue order: its key / sort buffers exist before the first launch (all or nothing)
+    if (h->opts.queue_order >= 2) {   // cold-queue order: its key / sort buffers exist before the first launch (all or nothing)
         rc = alloc_cold_queue(h);
         if (rc != SDDP_OK) { create_error() = h->err; sddp_destroy(h); return rc; }
     }
@@ -373,6 +386,8 @@ void sddp_destroy(sddp_handle* h) {
     if (h->first_dev) (void)hipFree(h->first_dev);
     if (h->box_dev) (void)hipFree(h->box_dev);
     if (h->xr_dev) (void)hipFree(h->xr_dev);
+    if (h->cls) (void)hipFree(h->cls);
+    if (h->cls_stat) (void)hipFree(h->cls_stat);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -679,6 +694,57 @@ int sddp_solve_resident_first(sddp_handle* h, double* u0_out, double* x1_out, do
         if (status_out) status_out[b] = int(r[h->d.nu + h->d.nx + 2]);
     }
     h->have_xws = true;
+    return SDDP_OK;
+}
+
+// class labels of the instances (queue_order = 3).  The class table is allocated on the first call; n_classes is fixed then.
+static int class_buffers(sddp_handle* h, int n_classes) {
+    if (n_classes < 1 || n_classes > (1 << 20)) return fail(h, SDDP_ERR_ARG, "n_classes must be 1 .. 2^20");
+    if (h->cls) {
+        if (n_classes != h->n_cls) return fail(h, SDDP_ERR_ARG, "n_classes differs from the first call's");
+        return SDDP_OK;
+    }
+    int* c = nullptr;
+    unsigned long long* st = nullptr;
+    hipError_t e = hipMalloc((void**)&c, size_t(h->B) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&st, size_t(n_classes) * 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(c, 0xFF, size_t(h->B) * sizeof(int), h->stream);       // -1: unlabelled
+    if (e == hipSuccess) e = hipMemsetAsync(st, 0, size_t(n_classes) * 2 * sizeof(unsigned long long), h->stream);
+    if (e != hipSuccess) {
+        if (c) (void)hipFree(c);
+        if (st) (void)hipFree(st);
+        return fail(h, SDDP_ERR_HIP, std::string("class buffers: ") + hipGetErrorString(e));
+    }
+    h->cls = c; h->cls_stat = st; h->n_cls = n_classes;
+    return SDDP_OK;
+}
+
+int sddp_set_instance_classes(sddp_handle* h, const int* classes, int n_classes) {
+    if (!h || !classes) return SDDP_ERR_ARG;
+    int rc = class_buffers(h, n_classes);
+    if (rc != SDDP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->cls, classes, size_t(h->B) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDDP_OK;
+}
+
+int sddp_set_instance_classes_range_device(sddp_handle* h, int first, int count, const int* d_classes, int n_classes) {
+    if (!h || !d_classes) return SDDP_ERR_ARG;
+    if (first < 0 || count < 1 || first > h->B - count) return fail(h, SDDP_ERR_ARG, "instance range outside the batch");
+    int rc = class_buffers(h, n_classes);
+    if (rc != SDDP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->cls + first, d_classes, size_t(count) * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    return SDDP_OK;
+}
+
+int sddp_class_history(sddp_handle* h, int cls, double* mean_iters, long long* solves) {
+    if (!h) return SDDP_ERR_ARG;
+    if (!h->cls || cls < 0 || cls >= h->n_cls) return fail(h, SDDP_ERR_ARG, "no such class");
+    unsigned long long st[2];
+    HIP_TRY(h, hipMemcpyAsync(st, h->cls_stat + 2 * cls, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (solves) *solves = (long long)st[1];
+    if (mean_iters) *mean_iters = st[1] ? double(st[0]) / double(st[1]) : 0.0;
     return SDDP_OK;
 }
 

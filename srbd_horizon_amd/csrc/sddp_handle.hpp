@@ -81,6 +81,10 @@ struct sddp_handle {
     int* order_in = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    // class history (queue_order = 3): the caller's class label per instance, and per class the iterations / solves so far
+    int* cls = nullptr;             // [B], -1: unlabelled
+    int n_cls = 0;
+    unsigned long long* cls_stat = nullptr;   // [n_cls][2]
     bool gains_by_instance = false; // the last solve launch ran instance b on slot b (no queue, first = 0): sddp_device_ptr(3)
     struct KInfo { const void* fn = nullptr; int slots = 0; };
     KInfo kinfo[2];                 // per kernel build: dynamic-LDS attribute set, resident workgroups on this device
@@ -122,5 +126,9 @@ inline int fail(sddp_handle* h, int code, const std::string& msg) {
 int alloc_cold_queue(sddp_handle* h);
 // queue order 1 (longest previous solve first): counting sort of [first, first + count) by h->hist into h->order, on the stream
 int launch_queue_order(sddp_handle* h, int first, int count);
+// queue order 3: h->qkey (initial costs of the launch's instances, order h->order_in) -> class-history keys; and the update of the
+// class statistics behind a solve launch
+int launch_class_keys(sddp_handle* h, int count);
+int launch_class_update(sddp_handle* h, int first, int count);
 
 }  // namespace sddp

@@ -34,6 +34,31 @@ __global__ __launch_bounds__(1024) void queue_order_kernel(int first, int count,
     }
 }
 
+// Queue order 3 (class history): the key of an instance is the mean iteration count that earlier solves of its CLASS took on this
+// handle (sddp_set_instance_classes: the caller's label of what kind of problem an instance is -- gait phase, command, ...), the
+// initial cost (the key of queue order 2, already in `key`) breaking ties inside a class; classes never solved before sort first.
+// cls_stat: [n_cls][2] = sum of iterations, solves.  The sum / count are read here and updated by class_update_kernel after the
+// solve launch, both on the handle's stream.
+__global__ __launch_bounds__(256) void class_key_kernel(int count, const int* __restrict__ idx, const int* __restrict__ cls, int n_cls,
+                                                        const unsigned long long* __restrict__ cls_stat, double* __restrict__ key) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const int c = cls[idx[i]];
+    double mean = 1e6;                                         // unlabelled instance / class without history: first
+    if (c >= 0 && c < n_cls && cls_stat[2 * c + 1] > 0) mean = double(cls_stat[2 * c]) / double(cls_stat[2 * c + 1]);
+    const double j0 = key[i];                                  // initial cost; non-finite: stays first
+    key[i] = (j0 == j0 && j0 < 1e300) ? mean + 1e-3 * j0 / (fabs(j0) + 1e9) : j0;      // tie-break in (-1e-3, 1e-3), monotone in j0
+}
+__global__ __launch_bounds__(256) void class_update_kernel(int first, int count, const int* __restrict__ cls, int n_cls,
+                                                           const sddp_stats* __restrict__ st, unsigned long long* __restrict__ cls_stat) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const int c = cls[first + i];
+    if (c < 0 || c >= n_cls) return;
+    atomicAdd(&cls_stat[2 * c], (unsigned long long)st[first + i].iters);
+    atomicAdd(&cls_stat[2 * c + 1], 1ull);
+}
+
 // what an MPC tick applies: the first input u_0 and the state the plan expects next, x_1, of every instance, packed
 // [B][nu + nx] (+ cost, iterations, status as three more doubles) for one small copy to the host instead of the whole trajectories
 __global__ __launch_bounds__(256) void first_knot_kernel(int N, int B, int nx, int nu, const double* __restrict__ xs,

@@ -104,12 +104,16 @@ int launch_solve(sddp_handle* h, SolveArgs a, int first, int count) {
             rc = launch_queue_order(h, first, count);
             if (rc != SDDP_OK) return rc;
             a.order = h->order;
-        } else if (h->opts.queue_order == 2) {     // largest initial cost first: keys by a pre-pass over the launch's instances
+        } else if (h->opts.queue_order >= 2) {     // largest initial cost first: keys by a pre-pass over the launch's instances
             rc = alloc_cold_queue(h);
             if (rc != SDDP_OK) return rc;
             hipLaunchKernelGGL(queue_cost_key_kernel<M>, dim3(count), dim3(kWave), 0, h->stream, a.c, a.N, first, count, a.x0, a.P, a.xs,
                                a.us, h->qkey, h->order_in);
             HIP_TRY(h, hipGetLastError());
+            if (h->opts.queue_order == 3 && h->cls) {   // ... longest class history first, the initial cost breaking ties
+                rc = launch_class_keys(h, count);
+                if (rc != SDDP_OK) return rc;
+            }
             HIP_TRY(h, sort_pairs_desc(h->sort_tmp, h->sort_tmp_bytes, h->qkey, h->qkey2, h->order_in, h->order, count, h->stream));
             a.order = h->order;
         }
@@ -122,6 +126,10 @@ int launch_solve(sddp_handle* h, SolveArgs a, int first, int count) {
     h->gains_by_instance = (count <= grid && first == 0);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, h->stream, a);
     HIP_TRY(h, hipGetLastError());
+    if (h->cls) {                                       // labelled instances: their iteration counts feed the class statistics
+        rc = launch_class_update(h, first, count);
+        if (rc != SDDP_OK) return rc;
+    }
     if (h->timing) {
         HIP_TRY(h, hipEventRecord(e1, h->stream));
         ++h->pending;

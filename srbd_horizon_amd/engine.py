@@ -235,6 +235,28 @@ class DdpEngine:
         """One asynchronous launch over the instances [first, first + count); `params` is the whole [B, N+1, np] tensor."""
         self._chk(self.lib.sddp_solve_range_device(self.h, self._dev(params, (self.B, self.N + 1, self.np_)), int(first), int(count)))
 
+    # ---- class history (queue_order = 3) -------------------------------------------------------------------------------------
+    def set_instance_classes(self, classes, n_classes: int):
+        """classes [B] int (host): what kind of problem each instance is (-1: unlabelled); sddp.h queue_order 3"""
+        c = np.ascontiguousarray(classes, dtype=np.int32)
+        if c.shape != (self.B,):
+            raise ValueError(f"expected {self.B} class labels")
+        self._chk(self.lib.sddp_set_instance_classes(self.h, _lib.ptr(c), int(n_classes)))
+
+    def set_instance_classes_range_device(self, first: int, count: int, classes, n_classes: int):
+        """labels of the instances [first, first + count) from a device int32 tensor (asynchronous on the handle's stream)"""
+        import torch
+        if not (isinstance(classes, torch.Tensor) and classes.is_cuda and classes.dtype == torch.int32 and classes.is_contiguous()
+                and tuple(classes.shape) == (count,)):
+            raise ValueError("expected a contiguous int32 CUDA tensor of `count` labels")
+        self._chk(self.lib.sddp_set_instance_classes_range_device(self.h, int(first), int(count), C.c_void_p(classes.data_ptr()), int(n_classes)))
+
+    def class_history(self, cls: int):
+        """-> (mean iterations, solves) of class `cls` on this handle so far"""
+        m, n = C.c_double(), C.c_longlong()
+        self._chk(self.lib.sddp_class_history(self.h, int(cls), C.byref(m), C.byref(n)))
+        return m.value, n.value
+
     RECORD_MODES = {"full": 0, "first_knot": 1}
 
     def record_words(self, mode="full"):

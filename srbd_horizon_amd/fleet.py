@@ -66,14 +66,17 @@ class FleetQueue:
     def full(self) -> bool:
         return self.pending == self.depth
 
-    def submit(self, x0, xs, us, params=None):
+    def submit(self, x0, xs, us, params=None, classes=None, n_classes=0):
         """One step: one batch of instances enters the queue (device tensors of `batch` instances; `params` [batch, N+1, np]
-        replaces that block's parameters).  Raises when the handle is full: flush first."""
+        replaces that block's parameters; `classes` [batch] int32 labels them for queue_order 3, sddp.h).  Raises when the handle
+        is full: flush first."""
         if self.pending == self.depth:
             raise RuntimeError("FleetQueue is full: flush() (and consume the results) before submitting another batch")
         lo = self.pending * self.batch
         if params is not None:
             self.P[lo:lo + self.batch].copy_(params)
+        if classes is not None:
+            self.eng.set_instance_classes_range_device(lo, self.batch, classes, n_classes)
         self.eng.load_range_device(lo, self.batch, x0, xs, us)
         self.pending += 1
 

@@ -192,3 +192,20 @@ MAKERS = {"srbd13": make_srbd13_batch, "srbd37": make_srbd37_batch, "lip30": mak
 
 def make_batch(model: str, N: int, seeds, robot: RobotModel | None = None):
     return MAKERS[model](N, seeds, robot)
+
+
+def srbd13_schedule_classes(params):
+    """Class label of every instance of an srbd13 batch (sddp.h queue_order 3): what the caller knows about the problem BEFORE it is
+    solved -- which feet are in stance at node 0, how many nodes until the first contact switch, and whether a forward / a lateral
+    velocity is commanded at the end of the horizon.  params [B, N+1, 19] (prb.py layout: rdot_ref 0:3, cdot_switch 17:19).
+    -> (labels [B] int32, n_classes)"""
+    P = np.asarray(params)
+    N = P.shape[1] - 1
+    sw = P[:, :, 17:19] > 0.5
+    stance0 = sw[:, 0, 0].astype(np.int64) * 2 + sw[:, 0, 1].astype(np.int64)                 # 0..3
+    changed = np.any(sw != sw[:, :1, :], axis=2)                                              # [B, N+1]
+    first_change = np.where(changed.any(axis=1), changed.argmax(axis=1), N + 1)               # 1..N, N+1: never
+    vx = (np.abs(P[:, N, 0]) > 1e-12).astype(np.int64)
+    vy = (np.abs(P[:, N, 1]) > 1e-12).astype(np.int64)
+    label = ((stance0 * (N + 2) + first_change) * 2 + vx) * 2 + vy
+    return label.astype(np.int32), 4 * (N + 2) * 4

@@ -92,7 +92,7 @@ def test_ranges_of_a_handle_solve_like_separate_batches():
 
 def test_non_finite_options_are_rejected():
     for k, v in (("alpha_0", float("inf")), ("mu_max", float("nan")), ("beta", float("nan")), ("gap_tol", float("inf")),
-                 ("mu_max", 1e-7), ("queue_order", 3), ("max_slots", -1), ("line_search_decrease_factor", 0.9999999), ("second_order", 3)):
+                 ("mu_max", 1e-7), ("queue_order", 4), ("max_slots", -1), ("line_search_decrease_factor", 0.9999999), ("second_order", 3)):
         with pytest.raises(RuntimeError):
             DdpEngine("srbd13", 30, 1, opts=dict(OPTS, **{k: v}))
 
@@ -173,3 +173,31 @@ def test_pack_records_kernel_writes_the_gather_record(mode):
         np.testing.assert_array_equal(out.cpu().numpy(), ref.numpy())
     with pytest.raises(RuntimeError):
         eng.pack_records_device(torch.empty((2, W), dtype=torch.float64, device=dev), B - 1, 2, mode)      # range past the batch
+
+
+def test_class_history_orders_the_queue_and_changes_no_result():
+    """queue_order = 3: instances labelled with a class; the handle learns the mean iteration count of each class from what it
+    solves and starts the longest classes first.  Results stay bit-identical to any other order; the order follows the class means."""
+    N, B = 30, 192
+    batch = workload.make_batch("srbd13", N, np.arange(B) + 100)
+    labels, ncls = workload.srbd13_schedule_classes(batch["params"])
+    assert labels.min() >= 0 and labels.max() < ncls and len(np.unique(labels)) >= 6
+    ref = _engine("srbd13", N, B)
+    x0, u0, s0 = _solve(ref, batch)
+    q = _engine("srbd13", N, B, max_slots=16, waves_per_simd=2, queue_order=3)
+    q.set_instance_classes(labels, ncls)
+    x, u, s = _solve(q, batch)                                        # no history yet: every class "unknown", ties by initial cost
+    np.testing.assert_array_equal(x, x0); np.testing.assert_array_equal(u, u0)
+    np.testing.assert_array_equal(s["iters"], s0["iters"])
+    for c in np.unique(labels)[:4]:                                   # the statistics are what was solved
+        m, n = q.class_history(int(c))
+        assert n == int((labels == c).sum()) and abs(m - s0["iters"][labels == c].mean()) <= 1e-12
+    x, u, s = _solve(q, batch)                                        # with history: by class mean
+    np.testing.assert_array_equal(x, x0); np.testing.assert_array_equal(u, u0)
+    order = q.last_queue_order()
+    assert sorted(order.tolist()) == list(range(B))
+    means = {int(c): s0["iters"][labels == c].mean() for c in np.unique(labels)}
+    km = np.array([means[int(labels[i])] for i in order])
+    assert np.all(np.diff(km) <= 1e-9)                                # descending class means along the queue
+    with pytest.raises(RuntimeError):
+        q.set_instance_classes(labels, ncls + 1)                      # n_classes is fixed by the first call
