@@ -37,7 +37,7 @@ def test_bench_defaults_and_contract_fields():
 
 def test_no_timed_instance_is_solved_before_the_timed_region():
     """every step solves instances of its own; the warm-up blocks are disjoint from every rank's timed blocks,
-    ranks do not share blocks, and the shipped default is the history-free queue order."""
+    ranks do not share blocks, and the shipped default order uses no history of the timed instances themselves."""
     for world, steps, warmup in ((1, 20, 5), (8, 20, 5), (2, 96, 16), (1, 1, 0), (4, 3, 7)):
         timed = [bench.seed_block(r, world, steps, warmup, "timed", i, run=k) for k in range(bench.RUNS) for r in range(world) for i in range(steps)]
         warm = [bench.seed_block(r, world, steps, warmup, "warmup", i) for r in range(world) for i in range(warmup)]
@@ -46,7 +46,9 @@ def test_no_timed_instance_is_solved_before_the_timed_region():
         assert sorted(timed) == list(range(bench.RUNS * world * steps))   # region k, rank r owns the contiguous blocks (k*world + r)*steps ..
         assert sorted(timed[:world * steps]) == list(range(world * steps))
     src = open(bench.__file__).read()
-    assert '"--queue-order", type=int, default=2' in src              # `value` = largest initial cost first: no history
+    # `value` = longest class history first: the classes are schedule features, the history is OTHER instances (the warm-up steps
+    # and earlier regions); nothing of a timed instance's solution is known when it starts
+    assert '"--queue-order", type=int, default=3' in src
     assert "replay_history_order_solves_per_s" in src                 # the foreknowledge figure is an extra, named as a replay
 
 
@@ -91,3 +93,16 @@ def test_steps_per_launch():
     assert bench.steps_per_launch(20, 8, launches_per_region=2) == 10 and bench.steps_per_launch(5, 2, launches_per_region=2) == 3
     assert bench.steps_per_launch(20, 8, launches_per_region=4) == 5 and bench.steps_per_launch(96, 1, queue_depth=64) == 64
     assert bench.steps_per_launch(1, 8, launches_per_region=2) == 1
+
+
+def test_class_labels_use_nothing_but_the_schedule():
+    """queue_order 3's labels (workload.srbd13_schedule_classes): functions of the parameter tensor alone -- the contact schedule
+    and the command -- not of the initial state, the warm start or anything a solve produces."""
+    from srbd_horizon_amd import workload
+    a = workload.make_srbd13_batch(30, np.arange(64))
+    b = workload.make_srbd13_batch(30, np.arange(64), x0_draw=1)              # same robots and schedules, another initial state
+    la, n = workload.srbd13_schedule_classes(a["params"])
+    lb, _ = workload.srbd13_schedule_classes(b["params"])
+    np.testing.assert_array_equal(la, lb)
+    assert not np.array_equal(a["x0"], b["x0"])
+    assert la.dtype == np.int32 and la.min() >= 0 and la.max() < n and len(np.unique(la)) > 4
