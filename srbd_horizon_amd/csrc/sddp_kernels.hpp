@@ -36,6 +36,13 @@ constexpr int kScal = 24;  // doubles per instance in the scratch `scal` record 
 #define SDDP_T_ARG , unsigned long long* T_, unsigned long long& t_last_
 #define SDDP_T_PASS , T_, t_last_
 #define SDDP_TICK(i) { const unsigned long long t_ = clock64(); T_[i] += t_ - t_last_; t_last_ = t_; }
+#elif defined(SDDP_MARKS)
+// Listing build only (-DSDDP_MARKS, `hipcc -S`): the phase boundaries as assembler comments, for tools/isa_phase_mix.py.  No
+// instruction is emitted; the volatile asm only keeps the compiler from moving code across a boundary.
+#define SDDP_T_DECL
+#define SDDP_T_ARG
+#define SDDP_T_PASS
+#define SDDP_TICK(i) asm volatile("; SDDP_MARK " #i ::: "memory");
 #else
 #define SDDP_T_DECL
 #define SDDP_T_ARG
