@@ -402,17 +402,41 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
         for (int t = 0; t < RGW; ++t)
             if (lane + t * kWave < NGW) gk[lane + t * kWave] = v[t];
     };
+    // Experiment (-DSDDP_LDS_DMA, profiles/r05/experiments): the knot's record | parameters | defect go HBM/L2 -> LDS by LDS-DMA
+    // (global_load_lds: lane l's bytes land at M0 + size * l, no VGPR round trip, no ds_write), issued for knot k - 1 where knot
+    // k's copies are dead (behind the Q phase) and waited for at the top of knot k - 1.  Record: NREC * 8 bytes = a whole number of
+    // 16-byte pieces, 16-byte aligned; parameters and defect rows are only 8-byte aligned: 4-byte pieces.
+#ifdef SDDP_LDS_DMA
+    constexpr bool kDma = (NREC * 8) % 16 == 0 && NREC * 8 / 16 <= kWave && NP * 2 <= kWave && NX * 2 <= kWave;
+#else
+    constexpr bool kDma = false;
+#endif
+    auto dma_fetch = [&](int k) {
+        typedef const __attribute__((address_space(1))) void* gptr;
+        typedef __attribute__((address_space(3))) void* lptr;
+        const char* rk = reinterpret_cast<const char*>(rec + size_t(k) * NREC);
+        const char* pk = reinterpret_cast<const char*>(P + size_t(k) * NP);
+        const char* dk = reinterpret_cast<const char*>(dft + size_t(k) * NX);
+        if (lane < NREC * 8 / 16) __builtin_amdgcn_global_load_lds((gptr)(rk + 16 * lane), (lptr)(s + L::REC), 16, 0, 0);
+        if (lane < NP * 2) __builtin_amdgcn_global_load_lds((gptr)(pk + 4 * lane), (lptr)(s + L::PK), 4, 0, 0);
+        if (has_gap && lane < NX * 2) __builtin_amdgcn_global_load_lds((gptr)(dk + 4 * lane), (lptr)(s + L::DK), 4, 0, 0);
+    };
     drain_vmem();
-    fetch(N - 1);
+    if constexpr (kDma) dma_fetch(N - 1); else fetch(N - 1);
     for (int k = N - 1; k >= 0; --k) {
-        // ---- stage this knot from the prefetch registers; start the next knot's loads; then the previous knot's gains go out
+        if constexpr (kDma) {
+            drain_vmem();                                    // this knot's operands have landed (issued a knot ago)
+            if (k < N - 1) store_gains(k + 1);
+        } else {
+            // ---- stage this knot from the prefetch registers; start the next knot's loads; then the previous knot's gains go out
 #pragma unroll
-        for (int t = 0; t + 1 < RREC; ++t) s[L::REC + lane + t * kWave] = r_rec[t];
-        if (t_on) s[t_dst] = r_rec[RREC - 1];
-        if (!MERGE_P && lane < NP) s[L::PK + lane] = r_p;
-        if (has_gap && lane < NX) s[L::DK + lane] = r_d;
-        if (k < N - 1) store_gains(k + 1);
-        if (k > 0) fetch(k - 1);
+            for (int t = 0; t + 1 < RREC; ++t) s[L::REC + lane + t * kWave] = r_rec[t];
+            if (t_on) s[t_dst] = r_rec[RREC - 1];
+            if (!MERGE_P && lane < NP) s[L::PK + lane] = r_p;
+            if (has_gap && lane < NX) s[L::DK + lane] = r_d;
+            if (k < N - 1) store_gains(k + 1);
+            if (k > 0) fetch(k - 1);
+        }
         wave_sync();
         SDDP_TICK(1)
         const double state = k >= 1 ? 1.0 : 0.0;
@@ -564,6 +588,7 @@ __device__ bool backward_sweep(const DevConsts& c, int N, const double* __restri
             wave_sync();
         }
         SDDP_TICK(4)
+        if constexpr (kDma) { if (k > 0) dma_fetch(k - 1); }   // REC / PK / DK of this knot are dead from here on
         // ---- [k K] = -Quu^-1 [Qu Qux]: Gauss-Jordan, lane j owns column j of [Quu+mu I | Qu | Qux]
         double a[NU];
         const double qx = s[L::QV + (lane > NU && lane < NCOL ? lane - NU - 1 : 0)];     // Qx of this lane's state column, for the Vx update
