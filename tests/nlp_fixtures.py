@@ -21,6 +21,10 @@ def load_all():
         c = json.loads(str(z["consts_json"]))
         d["consts"] = {k: (v[0] if len(v) == 1 else np.asarray(v)) for k, v in c.items()}
         d["consts"]["inertia_mode"] = int(d["consts"]["inertia_mode"])
+        if "relative_velocity_constraints" in d["consts"]:
+            d["consts"]["relative_velocity_constraints"] = int(d["consts"]["relative_velocity_constraints"])
+        if "extra_rows_json" in z.files:                     # user-declared linear rows (the params carry 8 more columns)
+            d["consts"]["extra_rows"] = tuple(dict(r, a=np.asarray(r["a"])) for r in json.loads(str(z["extra_rows_json"])))
         d["consts"]["I"] = d["consts"]["I"].reshape(3, 3)
         d["consts"]["feet"] = d["consts"]["feet"].reshape(-1, 3)
         d["name"] = os.path.basename(f)[:-4]

@@ -91,6 +91,10 @@ def _build(name, cst):
         nx, nu, npar = 61, 48, 27
     else:
         nx, nu, npar = 30, 15, 11
+    rows = list(getattr(cst, "extra_rows", None) or ())      # user-declared linear residual rows: 8 more parameter columns
+    npb = npar
+    if rows:
+        npar += 8
     x = sp.Matrix(sp.symbols(f"x0:{nx}"))
     u = sp.Matrix(sp.symbols(f"u0:{nu}"))
     p = sp.Matrix(sp.symbols(f"p0:{npar}"))
@@ -139,8 +143,12 @@ def _build(name, cst):
                 *(sp.sqrt(cst.min_qddot_gain) * sp.Matrix([*rddot, *cdd[0], *cdd[1], *cdd[2], *cdd[3]]))]
         ires += _penalties(cs, cds, [p[3 + 2 * i] for i in range(4)], [p[4 + 2 * i] for i in range(4)],
                            getattr(cst, "relative_velocity_constraints", True))
-    f = x + dt * xdot
     z_all = sp.Matrix([*x, *u])
+    for j, r in enumerate(rows):                             # sqrt(w) (a . z - (p[np + j] + const)): state rows (nodes 1..N) or stage rows
+        a = np.asarray(r["a"], dtype=float)
+        e = sp.sqrt(r["w"]) * (sum(float(a[i]) * z_all[i] for i in range(nx + nu) if a[i] != 0.0) - p[npb + j] - float(r.get("const", 0.0)))
+        (sres if r["kind"] == "state" else ires).append(e)
+    f = x + dt * xdot
     out = {}
     args = (list(x), list(u), list(p))
     lam = lambda e: sp.lambdify(args, e, "numpy", cse=True)
@@ -156,10 +164,12 @@ def _build(name, cst):
 
 
 @functools.lru_cache(maxsize=None)
-def second_order_symbolic(name, inertia_mode=0, lever_sign=1.0, rel_vel=True):
-    """lambda (x, u, p, vp) -> Hessian_z[vp.f + L_k] - 2 J^T J  (stage node k >= 1: input and state residuals), symbolic."""
+def second_order_symbolic(name, inertia_mode=0, lever_sign=1.0, rel_vel=True, rows_key=None):
+    """lambda (x, u, p, vp) -> Hessian_z[vp.f + L_k] - 2 J^T J  (stage node k >= 1: input and state residuals), symbolic.
+    rows_key: key into EXTRA_ROWS (user-declared linear rows; hashable for the cache)."""
     from oracle.models import RobotConsts
-    sym = _build(name, RobotConsts(inertia_mode=inertia_mode, lever_sign=lever_sign, relative_velocity_constraints=rel_vel))
+    sym = _build(name, RobotConsts(inertia_mode=inertia_mode, lever_sign=lever_sign, relative_velocity_constraints=rel_vel,
+                                   extra_rows=EXTRA_ROWS.get(rows_key)))
     x, u, p, f, ires_m, sres_m, z_all = sym["_sym"]
     vp = sp.Matrix(sp.symbols(f"v0:{len(x)}"))
     res = sp.Matrix([*ires_m, *sres_m])
@@ -175,10 +185,14 @@ def second_order_symbolic(name, inertia_mode=0, lever_sign=1.0, rel_vel=True):
             H += 2 * res[j] * Hj
     return sp.lambdify((list(x), list(u), list(p), list(vp)), H, "numpy", cse=True)
 
+EXTRA_ROWS = {}      # rows_key -> tuple of row dicts (registered by the caller: lru_cache needs hashable arguments)
+
+
 @functools.lru_cache(maxsize=None)
-def symbolic(name, inertia_mode=0, lever_sign=1.0, rel_vel=True):   # the consts object is returned so that callers can key caches on it
+def symbolic(name, inertia_mode=0, lever_sign=1.0, rel_vel=True, rows_key=None):   # the consts object is returned so that callers can key caches on it
     from oracle.models import RobotConsts
-    cst = RobotConsts(inertia_mode=inertia_mode, lever_sign=lever_sign, relative_velocity_constraints=rel_vel)
+    cst = RobotConsts(inertia_mode=inertia_mode, lever_sign=lever_sign, relative_velocity_constraints=rel_vel,
+                      extra_rows=EXTRA_ROWS.get(rows_key))
     return _build(name, cst), cst
 
 

@@ -49,3 +49,13 @@ def test_results_do_not_depend_on_what_the_lds_held(model, N, wps):
     for a, b in zip(clean, dirty):
         assert np.all(np.isfinite(b)), "a NaN out of the poisoned LDS reached the result"
         assert np.array_equal(a, b)
+
+
+def test_poison_hook_of_the_test_run_is_armed_when_asked_for():
+    """SDDP_POISON_LDS=1: tests/conftest.py wraps every launching entry point of the loaded library (the library itself reads no
+    environment variable); without the variable nothing is wrapped."""
+    import ctypes
+    import os
+    from srbd_horizon_amd import _lib
+    wrapped = not isinstance(_lib.load().sddp_solve, ctypes._CFuncPtr)
+    assert wrapped == (os.environ.get("SDDP_POISON_LDS") == "1")
