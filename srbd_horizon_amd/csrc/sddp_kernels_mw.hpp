@@ -625,8 +625,58 @@ __device__ __forceinline__ bool backward_sweep_mw(const DevConsts& c, int N, con
             __syncthreads();
         }
         SDDP_TICK(4)
-        // ---- [k K] = -Quu^-1 [Qu Qux]: block Gauss-Jordan, column (lane + 64 cc) of [Quu+mu I | Qu | Qux] in slot cc of a lane, wave w = rows w RPW ..
-        {
+#ifdef SDDP_GJ_REDUNDANT
+        constexpr bool kGjRedundant = NU <= 24 && NU + (NX + 1 + kWavesMW - 1) / kWavesMW <= kWave;
+#else
+        constexpr bool kGjRedundant = false;
+#endif
+        if constexpr (kGjRedundant) {
+            // Experiment (profiles/r05/experiments): NO hand-off inside the solve.  Every wave eliminates the
+            // whole [Quu + mu I] block REDUNDANTLY (lanes 0..NU-1: one column each, all NU rows in registers) together with ITS
+            // quarter of the right-hand sides [Qu | Qux] (lanes NU..NU+CW-1); pivot columns by v_readlane inside the wave.  The four
+            // waves compute the same pivots bit for bit, so the positive-definiteness decision needs no exchange.
+            constexpr int CW = (NX + 1 + kWavesMW - 1) / kWavesMW;
+            const int rc = wave * CW + (lane - NU);                       // right-hand side this lane holds: 0 = Qu, c + 1 = Qux column c
+            const bool is_rhs = lane >= NU && lane < NU + CW && rc <= NX;
+            const int qc = lane < NU ? NX + lane : (is_rhs && rc > 0 ? rc - 1 : 0);
+            double a[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                double v = s[L::QU + i * SQ + qc];
+                v = (is_rhs && rc == 0) ? s[L::QV + NX + i] : v;
+                v += (i == lane) ? mu : 0.0;
+                a[i] = (lane < NU || is_rhs) ? v : 0.0;
+            }
+            if (is_rhs && rc == 0) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) qu_acc = fmax(qu_acc, fabs(a[i]));
+            }
+            SDDP_TICK(16)
+            bool okp = true;
+#pragma unroll
+            for (int p = 0; p < NU; ++p) {
+                double pv[NU];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) pv[i] = readlane_d(a[i], p);
+                if (!(pv[p] > 0.0) || !(pv[p] < 1e300)) okp = false;
+                const double t = a[p] * fast_rcp(pv[p]);
+#pragma unroll
+                for (int i = 0; i < NU; ++i) a[i] = (i == p) ? t : fma(-pv[i], t, a[i]);
+            }
+            if (!okp) return false;                                       // the same in every wave
+            SDDP_TICK(19)
+            if (is_rhs) {
+                double* dst = rc == 0 ? s + L::KF : s + L::KT + (rc - 1) * SK;
+                double dv = 0.0;
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    dst[i] = -a[i];
+                    if (rc == 0) dv += -a[i] * s[L::QV + NX + i];
+                }
+                // dv_acc / qu_acc are read from lane NU of every wave at the end of the sweep: the Qu column is lane NU of wave 0
+                if (rc == 0) dv_acc += dv;
+            }
+        } else {
             double a[RPW][CPL], qu_save[RPW];
             // column of Q a slot reads (any valid one for the slot of column NU, which takes q instead; columns >= NCOL are zeroed): branch-free
             int qcol[CPL];
