@@ -62,6 +62,7 @@ def run(ns, actions, c_init_z, nc=4, contact_model=2, number_of_legs=2):
     out["actions"] = np.array(actions)
     out["c_init_z"] = np.array(c_init_z)
     out["ns"] = np.array(ns)
+    out["number_of_legs"], out["contact_model"] = np.array(number_of_legs), np.array(contact_model)
     return out
 
 
@@ -71,6 +72,10 @@ def main():
     for ns in (20, 30, 60):
         np.savez_compressed(os.path.join(OUT, f"wpg_step_ns{ns}.npz"), **run(ns, ["step"] * 45, 0.0))
         np.savez_compressed(os.path.join(OUT, f"wpg_mixed_ns{ns}.npz"), **run(ns, mixed, 0.02))
+    # the other contact configurations the problem builder accepts (prb.py:39-41): eight points (contact_model = 4, the default in
+    # the code) and four point feet (number_of_legs = 4 x contact_model = 1)
+    np.savez_compressed(os.path.join(OUT, "wpg_mixed_ns20_l2c4.npz"), **run(20, mixed, 0.02, nc=8, contact_model=4, number_of_legs=2))
+    np.savez_compressed(os.path.join(OUT, "wpg_mixed_ns20_l4c1.npz"), **run(20, mixed, 0.02, nc=4, contact_model=1, number_of_legs=4))
     print("wrote", sorted(f for f in os.listdir(OUT) if f.startswith("wpg_")))
 
 
