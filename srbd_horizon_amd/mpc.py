@@ -24,15 +24,21 @@ EXAMPLE_OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
 
 class MpcLoop:
     def __init__(self, model: str = "srbd37", ns: int = 20, T: float | None = None, opts: dict | None = None, robot=None,
-                 warm_start: str = "shift"):
+                 warm_start: str = "shift", number_of_legs: int = 2, contact_model: int | None = None):
         """warm_start: "shift" = previous solution advanced by one knot (last knot repeated),
         "device" = the same, with the parameter tensor and the warm start resident on the GPU and shifted there (only the new
         last parameter column and the state cross PCIe), "previous" = previous solution as is (what a stateful pyddp object
         would keep), "reset" = x0 repeated / static input."""
         T = ns * 0.05 if T is None else T                              # wpg hard-codes dt = 0.05 (wpg.py:20)
+        legs = 2
         if model in ("srbd37", "srbd61"):
+            # rosparams number_of_legs / contact_model (prb.py:39-40): srbd37 = 2 x 2 (the launch file's) or 4 x 1 (four point feet)
+            cm = contact_model if contact_model is not None else (2 if model == "srbd37" else 4)
+            legs = number_of_legs
             self.srbd = SRBDProblem()
-            self.srbd.createSRBDProblem(ns, T, robot, params=dict(contact_model=2 if model == "srbd37" else 4))
+            self.srbd.createSRBDProblem(ns, T, robot, params=dict(contact_model=cm, number_of_legs=legs))
+            if self.srbd.prb.model != model:
+                raise ValueError(f"number_of_legs = {legs}, contact_model = {cm} is model {self.srbd.prb.model}, not {model}")
             contact_model = self.srbd.contact_model
         elif model == "srbd13":
             self.srbd = SRBD13Problem()
@@ -55,7 +61,7 @@ class MpcLoop:
         self.state = self.srbd.getInitialState().astype(float)
         c_init_z = float(self.srbd.initial_foot_position[0][2])
         self.wpg = _wpg.steps_phase(self.srbd.f, self.srbd.c, self.srbd.cdot, c_init_z, self.srbd.c_ref, self.srbd.w_ref,
-                                    self.srbd.orientation_tracking_gain, self.srbd.cdot_switch, ns, number_of_legs=2,
+                                    self.srbd.orientation_tracking_gain, self.srbd.cdot_switch, ns, number_of_legs=legs,
                                     contact_model=contact_model)
         # warm start the first solve like dsrbd_example.py:61-68 computes it (x = state at every node, u = static input)
         self.solver.set_x_warmstart(np.repeat(self.state[:, None], ns + 1, axis=1))

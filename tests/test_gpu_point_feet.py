@@ -73,3 +73,17 @@ def test_builder_surface_with_four_point_feet():
     assert np.max(np.abs(sol["x_opt"].T - r.xs)) <= 1e-6 and np.max(np.abs(sol["u_opt"].T - r.us)) <= 1e-6
     # the four feet may now move apart inside a "foot": cdot0 - cdot1 is free (it is pinned to 0 with contact_model = 2)
     assert sol["cdot0"].shape == (3, ns + 1)
+
+
+def test_receding_horizon_loop_with_four_point_feet():
+    """dsrbd_example.py:82-185 (mpc.MpcLoop) on number_of_legs = 4 x contact_model = 1: the scheduler drives contact 0 with the
+    left cycle and 1..3 with the right one (wpg.py:84-88), the loop walks and every tick converges."""
+    from srbd_horizon_amd.mpc import MpcLoop
+    loop = MpcLoop(model="srbd37", ns=20, number_of_legs=4, contact_model=1)
+    assert loop.solver.ddp_solver.consts.relative_velocity_constraints == 0
+    out = loop.run(40, motion="walking", axes=(1.0, 0.0))
+    assert all(o for o in out)                                            # converged every tick
+    x = loop.state
+    assert np.all(np.isfinite(x)) and 0.7 < x[2] < 1.0 and x[0] > 0.05    # upright, moved forward
+    with pytest.raises(ValueError):
+        MpcLoop(model="srbd61", ns=20, number_of_legs=4, contact_model=1)
