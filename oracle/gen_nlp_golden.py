@@ -171,9 +171,12 @@ def main(which=None):
     os.makedirs(OUT, exist_ok=True)
     jobs = [("srbd13", 30, [0, 1, 5, 12]),     # seeds 5, 12: commanded-velocity instances (rdot_ref at the last node != 0)
             ("srbd37", 20, [0, 3]),
-            ("lip30", 20, [5])]
+            ("lip30", 20, [5]),
+            ("srbd37", 60, [2])]               # BASELINE configs[4]: N = 60, every defect open at the start
     for name, N, seeds in jobs:
-        if which and name not in which:
+        if which and name not in which and f"{name}_n{N}" not in which:
+            continue
+        if which and f"{name}_n{N}" not in which and any(w.startswith(name + "_n") for w in which):
             continue
         batch = workload.make_batch(name, N, seeds)
         for j, seed in enumerate(seeds):
