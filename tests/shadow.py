@@ -133,7 +133,7 @@ def engine_states(model, N, opts, consts, x0, P, xs, us, kmax):
     return states
 
 
-def first_split(states, trace):
+def first_split(states, trace, opts_alpha0=1.0, opts_factor=0.5):
     """First accepted step at which the engine (states, or a second oracle line-search trace) and a full oracle run (its
     line-search trace) take different step lengths, and how far their costs had drifted apart BEFORE that step.
     -> dict or None (same step lengths throughout)."""
@@ -146,8 +146,16 @@ def first_split(states, trace):
     for k in range(min(len(seq), len(acc))):
         if seq[k][1] != acc[k]["alpha"]:
             J = max(abs(acc[k]["J"]), 1e-300)
+            # the oracle's own Armijo margin (relative to |J|) for the step length the engine took, where the oracle tried it:
+            # > 0 = the oracle rejected it.  Not at rounding level: the two sides are no longer at the same iterate (drift_before)
+            margins, a, j, m_rel = acc[k]["margin"], opts_alpha0, 0, None
+            while j < len(margins) and a > seq[k][1] * (1 + 1e-12):
+                a *= opts_factor; j += 1
+            if j < len(margins) and abs(a - seq[k][1]) <= 1e-12 * a:
+                m_rel = float(margins[j] / J)
             return dict(step=k + 1, alpha_engine=float(seq[k][1]), alpha_oracle=float(acc[k]["alpha"]),
-                        drift_before=float(abs(seq[k][0] - acc[k]["J"]) / J))
+                        drift_before=float(abs(seq[k][0] - acc[k]["J"]) / J), oracle_margin_rel_at_engine_alpha=m_rel,
+                        oracle_margin_rel_at_its_own_alpha=float(margins[-1] / J) if len(margins) else None)
     return None
 
 
@@ -219,6 +227,9 @@ def parity_record(res):
                 both=len(set(r["instance"] for r in ex) & set(res["cpu_pair_idx"].tolist())),
                 instances=[dict(i=r["instance"], it=(r["gpu_iters"], r["oracle_iters"], r["oracle_fast_iters"]),
                                 split=(r["split_gpu"] or {}).get("step"), drift=(r["split_gpu"] or {}).get("drift_before"),
+                                alphas=((r["split_gpu"] or {}).get("alpha_engine"), (r["split_gpu"] or {}).get("alpha_oracle")),
+                                margin=((r["split_gpu"] or {}).get("oracle_margin_rel_at_engine_alpha"),
+                                        (r["split_gpu"] or {}).get("oracle_margin_rel_at_its_own_alpha")),
                                 cpu_split=(r["split_cpu_fast"] or {}).get("step"), cpu_drift=(r["split_cpu_fast"] or {}).get("drift_before"),
                                 step_max=r["shadow"]["max_rel_cost"], step_med=r["shadow"]["median_rel_cost"],
                                 ratio=r["shadow"]["max_ratio"], unstable=r["shadow"]["unstable_steps"],
