@@ -172,7 +172,8 @@ def main(which=None):
     jobs = [("srbd13", 30, [0, 1, 5, 12]),     # seeds 5, 12: commanded-velocity instances (rdot_ref at the last node != 0)
             ("srbd37", 20, [0, 3]),
             ("lip30", 20, [5]),
-            ("srbd37", 60, [2])]               # BASELINE configs[4]: N = 60, every defect open at the start
+            ("srbd37", 60, [2]),               # BASELINE configs[4]: N = 60, every defect open at the start
+            ("srbd61", 20, [1])]               # the code-default contact model (prb.py:39-41: 2 legs x 4 sole corners)
     for name, N, seeds in jobs:
         if which and name not in which and f"{name}_n{N}" not in which:
             continue

@@ -13,7 +13,7 @@ FIXTURES = nf.load_all()
 def test_fixture_set_is_what_the_design_lists():
     names = sorted(f["name"] for f in FIXTURES)
     assert sum(n.startswith("nlp_srbd13_n30") for n in names) >= 4 and sum(n.startswith("nlp_srbd37_n20") for n in names) >= 2
-    assert any(n.startswith("nlp_lip30") for n in names)
+    assert any(n.startswith("nlp_lip30") for n in names) and any(n.startswith("nlp_srbd61") for n in names)
     # at least one commanded-velocity instance per SRBD model (rdot_ref at the last node != 0)
     for m in ("srbd13", "srbd37"):
         assert any(f["model"] == m and np.any(f["params"][-1, 0:3] != 0.0) for f in FIXTURES)
