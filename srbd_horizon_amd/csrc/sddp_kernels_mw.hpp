@@ -707,10 +707,41 @@ __device__ __forceinline__ bool backward_sweep_mw(const DevConsts& c, int N, con
                 double* gt = s + L::GT + (blk & 1) * RPW * GTS;
                 if (wave == blk) {
                     bool ok = true;
+#ifdef SDDP_GJ_PAIR
+                    // Experiment (profiles/r05/experiments #11): the owner's pivots two at a time -- the 2 x 2 diagonal block is
+                    // inverted with ONE reciprocal (of its determinant) and both pivot columns are fetched before either is used, so
+                    // the serial chain readlane -> reciprocal -> scale -> update runs RPW / 2 times per block instead of RPW times.
+                    // Positive definite <=> a00 > 0 and det > 0 (the second pivot of the one-at-a-time order is det / a00).
+#pragma unroll
+                    for (int r = 0; r + 1 < RPW; r += 2) {
+                        const int p = blk * RPW + r;
+                        if (p + 1 < NU) {
+                            double p0[RPW], p1[RPW];
+#pragma unroll
+                            for (int rr = 0; rr < RPW; ++rr) { p0[rr] = readlane_d(a[rr][0], p); p1[rr] = readlane_d(a[rr][0], p + 1); }
+                            const double det = fma(p0[r], p1[r + 1], -p1[r] * p0[r + 1]);
+                            if (!(p0[r] > 0.0) || !(det > 0.0) || !(det < 1e300)) ok = false;
+                            const double id = fast_rcp(det);
+                            const double i00 = p1[r + 1] * id, i01 = -p1[r] * id, i10 = -p0[r + 1] * id, i11 = p0[r] * id;
+#pragma unroll
+                            for (int cc = 0; cc < CPL; ++cc) {
+                                const double t0 = fma(i00, a[r][cc], i01 * a[r + 1][cc]);
+                                const double t1 = fma(i10, a[r][cc], i11 * a[r + 1][cc]);
+#pragma unroll
+                                for (int rr = 0; rr < RPW; ++rr)
+                                    a[rr][cc] = (rr == r) ? t0 : (rr == r + 1) ? t1 : fma(-p1[rr], t1, fma(-p0[rr], t0, a[rr][cc]));
+                            }
+                        }
+                    }
+                    // an odd last row of the block, or a last pivot without a partner, goes alone (always behind the pairs)
+                    auto paired = [&](int r) { return (r & ~1) + 1 < RPW && blk * RPW + (r & ~1) + 1 < NU; };
+#else
+                    auto paired = [](int) { return false; };
+#endif
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) {
                         const int p = blk * RPW + r;
-                        if (p < NU) {
+                        if (p < NU && !paired(r)) {
                             double pv[RPW];
 #pragma unroll
                             for (int rr = 0; rr < RPW; ++rr) pv[rr] = readlane_d(a[rr][0], p);
