@@ -175,14 +175,26 @@ def second_order_symbolic(name, inertia_mode=0, lever_sign=1.0, rel_vel=True, ro
     res = sp.Matrix([*ires_m, *sres_m])
     # only the non-linear rows contribute: sum_i vp_i Hess(f_i) + sum_j 2 res_j Hess(res_j)
     H = sp.zeros(len(z_all), len(z_all))
+    zl, zset = list(z_all), set(z_all)
+
+    def add_hessian(weight, e):
+        """H += weight * Hessian_z(e): upper triangle mirrored, second derivatives only of gradient entries that still depend on z
+        (most rows are linear: sp.hessian would differentiate all nz^2 entries of every one of them)"""
+        for a, za in enumerate(zl):
+            ga = sp.diff(e, za)
+            if not (ga.free_symbols & zset):
+                continue
+            for b in range(a, len(zl)):
+                h = sp.diff(ga, zl[b])
+                if h != 0:
+                    H[a, b] += weight * h
+                    if b != a:
+                        H[b, a] += weight * h
+
     for i in range(len(x)):
-        Hi = sp.hessian(f[i], list(z_all))
-        if any(e != 0 for e in Hi):
-            H += vp[i] * Hi
+        add_hessian(vp[i], f[i])
     for j in range(len(res)):
-        Hj = sp.hessian(res[j], list(z_all))
-        if any(e != 0 for e in Hj):
-            H += 2 * res[j] * Hj
+        add_hessian(2 * res[j], res[j])
     return sp.lambdify((list(x), list(u), list(p), list(vp)), H, "numpy", cse=True)
 
 EXTRA_ROWS = {}      # rows_key -> tuple of row dicts (registered by the caller: lru_cache needs hashable arguments)
