@@ -1,5 +1,8 @@
+"""TEST INFRASTRUCTURE ONLY -- round-5 experiment #6 (profiles/r05/experiments/README.md): Gauss-Newton multiple shooting with a LINEAR
+forward sweep instead of the nonlinear line-search rollout, on the numpy oracle's model code.  Not shipped, not imported by the product."""
 import numpy as np, sys, time
-sys.path.insert(0,'/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import cport, ddp as oddp, models as omodels
 from srbd_horizon_amd import workload
 

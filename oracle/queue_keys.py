@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""What is knowable about an instance's iteration count BEFORE its first iteration, and what each queue key buys (DESIGN.md
+"""TEST INFRASTRUCTURE ONLY (it runs the C oracle).  What is knowable about an instance's iteration count BEFORE its first iteration, and what each queue key buys (DESIGN.md
 section 5, "work queue").  CPU only: iteration counts from the plain-C oracle (test infrastructure; identical to
 the GPU's on > 99.8 % of the instances), makespans from the list-scheduling model of tools/queue_sim.py (2048 slots).
 
 Keys are FITTED on seed blocks 0..19 and EVALUATED on the held-out blocks 60..79 (bench.py times 0..59 at --steps 20).
 
-    python tools/queue_keys.py            # table in profiles/r05/queue_keys.txt
+    python oracle/queue_keys.py            # table in profiles/r05/queue_keys.txt
 """
 import os
 import sys
