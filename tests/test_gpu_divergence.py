@@ -25,7 +25,7 @@ OPTS = dict(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)      # dsr
 THREADS = min(16, os.cpu_count() or 1)
 
 
-def assert_batch(res, key, record_property, tripwire=True):
+def assert_batch(res, key, record_property, tripwire=True, same_optimum=True):
     x, u, st, xo, uo, so, same = (res[k] for k in ("x", "u", "st", "xo", "uo", "so", "same"))
     report_parity(record_property, key, **shadow.parity_record(res))
     # ---- same path: end-to-end parity at the north_star tolerance
@@ -42,7 +42,10 @@ def assert_batch(res, key, record_property, tripwire=True):
         # builds of the oracle split on as well
         sp = rec["split_gpu"]
         assert sp is None or sp["drift_before"] >= 1e-9 or rec["oracle_fast_iters"] != rec["oracle_iters"] or sp["step"] >= 20, rec
-        if rec["gpu_status"] == 0 and rec["oracle_status"] == 0:       # both converged: the same local optimum
+        # both converged: the same local optimum -- on every instance the tests and the bench touch.  (tests/soak_parity.py passes
+        # same_optimum=False and counts: over 204 800 further instances a handful of these crawls end in ANOTHER local optimum, for the
+        # GPU against the oracle as for one CPU build of the oracle against the other.)
+        if same_optimum and rec["gpu_status"] == 0 and rec["oracle_status"] == 0:
             assert rec["end_linf"] <= 1e-4, rec
     if tripwire:
         # a tripwire, not the parity statement: the GPU may split from the oracle about as often as the oracle splits from itself
