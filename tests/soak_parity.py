@@ -1,7 +1,7 @@
 """Soak run of the whole-batch parity statement of tests/test_gpu_divergence.py on instances NO test and no bench region ever
 touches (seed blocks 60 .. 60 + n): not collected by pytest (minutes of GPU time), run by hand on the GPU box:
 
-    python tests/soak_parity.py [first_block] [n_chunks] [blocks_per_chunk]  ->  one JSON line per chunk + a total
+    python tests/soak_parity.py [first_block] [n_chunks] [blocks_per_chunk] [model] [N]  ->  one JSON line per chunk + a total
 
 Asserts exactly what the test asserts (end-to-end parity on the same path; one-step shadowing of every accepted GPU step on the
 others) and reports the counts beside the number of instances on which the two CPU builds of the oracle split."""
@@ -21,15 +21,15 @@ from tests import shadow  # noqa: E402
 from tests.test_gpu_divergence import OPTS, THREADS, assert_batch  # noqa: E402
 
 
-def main(first, chunks, per):
-    N, B = 30, 1024
+def main(first, chunks, per, model="srbd13", N=30):
+    B = 1024
     tot = dict(instances=0, other_path=0, cpu_pair=0, both=0, unconverged_oracle=0, unconverged_gpu=0, other_optimum=0, worst_end_linf=0.0, worst_same_linf=0.0)
     for c in range(chunks):
         blocks = range(first + c * per, first + (c + 1) * per)
         seeds = np.concatenate([b * B + np.arange(B) for b in blocks])
         t0 = time.time()
-        batch = workload.make_srbd13_batch(N, seeds)
-        res = shadow.check_batch("srbd13", N, batch, OPTS, dict(waves_per_simd=2, queue_order=2), omodels.RobotConsts(**batch["consts"]),
+        batch = workload.make_batch(model, N, seeds)
+        res = shadow.check_batch(model, N, batch, OPTS, dict(waves_per_simd=2, queue_order=2), omodels.RobotConsts(**batch["consts"]),
                                  threads=THREADS)
         assert_batch(res, f"soak_{blocks[0]}_{blocks[-1]}", lambda *a, **k: None, same_optimum=False)
         # instances where both converge, but not to the same point: what do the two CPU builds of the oracle do on them?
@@ -39,7 +39,7 @@ def main(first, chunks, per):
             i = r["instance"]
             a = [batch[k][i:i + 1] for k in ("x0", "params", "xs", "us")]
             cst = omodels.RobotConsts(**batch["consts"])
-            xf, uf, sf = cport.solve_batch(cst, oddp.DdpOptions(**OPTS), *a, threads=1, variant="fast")
+            xf, uf, sf = cport.solve_batch(cst, oddp.DdpOptions(**OPTS), *a, threads=1, variant="fast", model=model)
             sp = r["split_gpu"] or {}
             other_rec.append(dict(seed=int(seeds[i]), it=(r["gpu_iters"], r["oracle_iters"], r["oracle_fast_iters"]), end_linf=r["end_linf"],
                                   end_rel_cost=r["end_rel_cost"], split_step=sp.get("step"), drift_before=sp.get("drift_before"),
@@ -66,5 +66,6 @@ def main(first, chunks, per):
 
 
 if __name__ == "__main__":
-    a = [int(v) for v in sys.argv[1:]]
-    main(a[0] if a else 60, a[1] if len(a) > 1 else 10, a[2] if len(a) > 2 else 20)
+    a = sys.argv[1:]
+    main(int(a[0]) if a else 60, int(a[1]) if len(a) > 1 else 10, int(a[2]) if len(a) > 2 else 20, a[3] if len(a) > 3 else "srbd13",
+         int(a[4]) if len(a) > 4 else 30)
