@@ -18,8 +18,8 @@ all-gather of the solution records when N > 1), on ONE stream.
 Why a queue: a batch ends with its slowest instance (up to 100 DDP iterations; the mean is 16) and 1024 instances do not fill
 2048 wavefront slots, so one launch per batch leaves most SIMD time idle.  A launch of a queue still ends with its slowest
 instance, so the order matters.  `value` is measured with `queue_order = 3`: every instance carries a CLASS label computed from
-its schedule before it is solved (which feet stand at node 0, nodes to the first contact switch, whether a forward / lateral
-velocity is commanded: srbd_horizon_amd.workload.srbd13_schedule_classes), the handle keeps the mean iteration count of every class
+its schedule before it is solved (which feet stand at node 0, nodes to the first contact switch, the commanded forward / lateral
+velocity as none / + / -: srbd_horizon_amd.workload.srbd13_schedule_classes), the handle keeps the mean iteration count of every class
 over the instances it has solved so far -- at the start of the first timed region: the warm-up steps, other instances -- and the
 queue starts the classes with the longest history first, the initial cost (a pre-pass of the launch) breaking ties.  No instance
 of a timed region has been solved before, nothing of its solution is known.  Reported beside it: `initial_cost_order_solves_per_s`
@@ -220,7 +220,7 @@ def drain_profile(slot_t):
 
 ORDER_NAMES = {0: "index", 1: "longest previous solve first (history of this handle)", 2: "largest initial cost first (pre-pass of the launch, no history)",
                3: "longest class history first: mean iterations of the instance's schedule class (stance at node 0, nodes to the first contact "
-                  "switch, commanded velocity pattern) over the OTHER instances this handle has solved -- here the warm-up steps; initial cost breaks ties"}
+                  "switch, commanded forward / lateral velocity: none, + or -) over the OTHER instances this handle has solved -- here the warm-up steps; initial cost breaks ties"}
 
 
 def main():
@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the single-instance extras")
     ap.add_argument("--queue-depth", type=int, default=64, help="steps (batches) one engine handle holds = most steps per launch")
+    ap.add_argument("--class-signs", type=int, default=1, help="queue order 3: class labels with the SIGN of the commanded velocity (0: zero / non-zero only)")
     ap.add_argument("--waves-per-simd", type=int, default=2, help="kernel build: 1 = one wavefront per SIMD, 2 = two")
     ap.add_argument("--queue-order", type=int, default=3, help="sddp_options.queue_order: 3 longest class history first (classes = schedule "
                                                               "features known before the solve; history = the warm-up steps), 2 largest initial "
@@ -286,7 +287,7 @@ def main():
         seeds = np.concatenate([b * B + np.arange(B) for b in blocks])
         h = workload.make_srbd13_batch(N, seeds, x0_draw=x0_draw)
         d = {k: torch.from_numpy(h[k]).to(dev).reshape((len(blocks), B) + h[k].shape[1:]) for k in ("x0", "xs", "us", "params")}
-        lab, ncls = workload.srbd13_schedule_classes(h["params"])       # what kind of problem each instance is (queue order 3)
+        lab, ncls = workload.srbd13_schedule_classes(h["params"], signed=bool(args.class_signs))   # what kind of problem each instance is (queue order 3)
         d["classes"], d["n_classes"] = torch.from_numpy(lab).to(dev).reshape(len(blocks), B), ncls
         return d
 

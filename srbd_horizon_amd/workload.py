@@ -194,10 +194,12 @@ def make_batch(model: str, N: int, seeds, robot: RobotModel | None = None):
     return MAKERS[model](N, seeds, robot)
 
 
-def srbd13_schedule_classes(params):
+def srbd13_schedule_classes(params, signed=True):
     """Class label of every instance of an srbd13 batch (sddp.h queue_order 3): what the caller knows about the problem BEFORE it is
-    solved -- which feet are in stance at node 0, how many nodes until the first contact switch, and whether a forward / a lateral
-    velocity is commanded at the end of the horizon.  params [B, N+1, 19] (prb.py layout: rdot_ref 0:3, cdot_switch 17:19).
+    solved -- which feet are in stance at node 0, how many nodes until the first contact switch, and the commanded forward / lateral
+    velocity at the end of the horizon as zero / positive / negative (signed=False: zero / non-zero, round 5's first labels; the sign
+    decides on which side of the stance foot the plan leads, and the list-scheduling model prices it at 1.15 against 1.23 x the
+    ideal makespan: profiles/r05/queue_keys.txt).  params [B, N+1, 19] (prb.py layout: rdot_ref 0:3, cdot_switch 17:19).
     -> (labels [B] int32, n_classes)"""
     P = np.asarray(params)
     N = P.shape[1] - 1
@@ -205,7 +207,10 @@ def srbd13_schedule_classes(params):
     stance0 = sw[:, 0, 0].astype(np.int64) * 2 + sw[:, 0, 1].astype(np.int64)                 # 0..3
     changed = np.any(sw != sw[:, :1, :], axis=2)                                              # [B, N+1]
     first_change = np.where(changed.any(axis=1), changed.argmax(axis=1), N + 1)               # 1..N, N+1: never
-    vx = (np.abs(P[:, N, 0]) > 1e-12).astype(np.int64)
-    vy = (np.abs(P[:, N, 1]) > 1e-12).astype(np.int64)
-    label = ((stance0 * (N + 2) + first_change) * 2 + vx) * 2 + vy
-    return label.astype(np.int32), 4 * (N + 2) * 4
+    nv = 3 if signed else 2
+
+    def cmd(v):                                                                               # 0: none, 1: positive, 2: negative
+        c = (np.abs(v) > 1e-12).astype(np.int64)
+        return c + ((v < -1e-12) & signed) if signed else c
+    label = ((stance0 * (N + 2) + first_change) * nv + cmd(P[:, N, 0])) * nv + cmd(P[:, N, 1])
+    return label.astype(np.int32), 4 * (N + 2) * nv * nv

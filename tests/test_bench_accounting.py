@@ -106,3 +106,7 @@ def test_class_labels_use_nothing_but_the_schedule():
     np.testing.assert_array_equal(la, lb)
     assert not np.array_equal(a["x0"], b["x0"])
     assert la.dtype == np.int32 and la.min() >= 0 and la.max() < n and len(np.unique(la)) > 4
+    # the default labels carry the SIGN of the commanded velocity; they refine the zero / non-zero labels of the first version
+    lu, nu = workload.srbd13_schedule_classes(a["params"], signed=False)
+    assert n == 4 * 32 * 9 and nu == 4 * 32 * 4 and len(np.unique(la)) > len(np.unique(lu))
+    assert all(len(np.unique(lu[la == c])) == 1 for c in np.unique(la))
