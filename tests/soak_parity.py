@@ -1,7 +1,7 @@
 """Soak run of the whole-batch parity statement of tests/test_gpu_divergence.py on instances NO test and no bench region ever
 touches (seed blocks 60 .. 60 + n): not collected by pytest (minutes of GPU time), run by hand on the GPU box:
 
-    python tests/soak_parity.py [first_block] [n_chunks] [blocks_per_chunk] [model] [N]  ->  one JSON line per chunk + a total
+    python tests/soak_parity.py [first_block] [n_chunks] [blocks_per_chunk] [model] [N] [option=int ...]  ->  one JSON line per chunk + a total
 
 Asserts exactly what the test asserts (end-to-end parity on the same path; one-step shadowing of every accepted GPU step on the
 others) and reports the counts beside the number of instances on which the two CPU builds of the oracle split."""
@@ -21,8 +21,9 @@ from tests import shadow  # noqa: E402
 from tests.test_gpu_divergence import OPTS, THREADS, assert_batch  # noqa: E402
 
 
-def main(first, chunks, per, model="srbd13", N=30):
+def main(first, chunks, per, model="srbd13", N=30, over=None):
     B = 1024
+    OPTS.update(over or {})                                  # e.g. second_order=2: solver options of both sides
     tot = dict(instances=0, other_path=0, cpu_pair=0, both=0, unconverged_oracle=0, unconverged_gpu=0, other_optimum=0, worst_end_linf=0.0, worst_same_linf=0.0)
     for c in range(chunks):
         blocks = range(first + c * per, first + (c + 1) * per)
@@ -68,4 +69,4 @@ def main(first, chunks, per, model="srbd13", N=30):
 if __name__ == "__main__":
     a = sys.argv[1:]
     main(int(a[0]) if a else 60, int(a[1]) if len(a) > 1 else 10, int(a[2]) if len(a) > 2 else 20, a[3] if len(a) > 3 else "srbd13",
-         int(a[4]) if len(a) > 4 else 30)
+         int(a[4]) if len(a) > 4 else 30, {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a[5:]})
