@@ -121,8 +121,8 @@ typedef struct sddp_model_consts {
      * holds (ddp.py:183-196, :216-226); the analytic models hard-wire prb.py's terms, and take on top up to SDDP_MAX_EXTRA rows
      *     r_j = sqrt(extra_weight[j]) * ( extra_a[j] . z  -  ( p[np + j] + extra_const[j] ) ),      z = [x u],
      * extra_kind[j] 0: a state row, active on nodes 1..N like prb.py's tracking terms (terminal node included; its coefficients on
-     * the inputs must be 0), 1: a stage row, nodes 0..N-1 like min_qddot.  n_extra > 0 selects the model's "_x" build (srbd13,
-     * srbd37, lip30; plain build only: no barrier, no second_order = 2), whose parameter vector is SDDP_MAX_EXTRA columns wider
+     * the inputs must be 0), 1: a stage row, nodes 0..N-1 like min_qddot.  n_extra > 0 selects the model's "_x" build (every
+     * model; plain build only: no barrier, no second_order = 2), whose parameter vector is SDDP_MAX_EXTRA columns wider
      * than sddp_model_dims says: columns np .. np + 7 of every node are the per-knot references of rows 0..7 (unused ones: 0);
      * sddp_handle_dims reports the handle's width.  (v9) */
     int    n_extra;

@@ -32,6 +32,7 @@ const ModelOps* ops_lip30();
 const ModelOps* ops_srbd61();
 const ModelOps* ops_srbd13_x();
 const ModelOps* ops_srbd37_x();
+const ModelOps* ops_srbd61_x();
 const ModelOps* ops_lip30_x();
 
 std::string& create_error() {
@@ -90,6 +91,7 @@ const ModelOps* model_ops(int id, bool bar = false, bool so2 = false, bool xr = 
             case SDDP_MODEL_SRBD13: return ops_srbd13_x();
             case SDDP_MODEL_SRBD37: return ops_srbd37_x();
             case SDDP_MODEL_LIP30: return ops_lip30_x();
+            case SDDP_MODEL_SRBD61: return ops_srbd61_x();
             default: return nullptr;
         }
     }
@@ -271,7 +273,7 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     const bool so2 = opts && opts->second_order == 2 && !single_build(model_id);     // (the LIP model is linear-quadratic: nothing to add)
     const bool xr = consts && consts->n_extra != 0;
     const ModelOps* ops = model_ops(model_id, bar, so2, xr);
-    if (!ops) return fail(nullptr, SDDP_ERR_ARG, xr ? "user rows (n_extra > 0) exist for the plain builds of srbd13, srbd37 and lip30 only (no barrier, no second_order = 2)"
+    if (!ops) return fail(nullptr, SDDP_ERR_ARG, xr ? "user rows (n_extra > 0) exist for the plain builds only (no barrier, no second_order = 2)"
                                                     : "this model has no barrier / second_order = 2 build (srbd61: default build only)");
     const Dims d = ops->dims;
     if (N < 1 || batch < 1) return fail(nullptr, SDDP_ERR_ARG, "N and batch must be >= 1");

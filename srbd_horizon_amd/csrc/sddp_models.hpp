@@ -1652,5 +1652,6 @@ using Lip30 = LipModel<>;
 using Srbd13X = SrbdModel<2, false, false, false, kXrRows>;   // with user-declared linear residual rows (sddp_model_consts.n_extra > 0)
 using Srbd37X = SrbdModel<4, true, false, false, kXrRows>;
 using Lip30X = LipModel<kXrRows>;
+using Srbd61X = SrbdModel<8, true, false, false, kXrRows>;
 
 }  // namespace sddp

@@ -1,5 +1,5 @@
 """User-declared linear residual rows (include/sddp.h extra_*; reference: ddp.py:183-196 / :216-226 sum whatever residual the
-function container holds): the "_x" builds of srbd13 / srbd37 / lip30 against both oracles -- per-knot evaluation, one sweep,
+function container holds): the "_x" builds of all four models against both oracles -- per-knot evaluation, one sweep,
 converged solves from the C-ABI level, and through the builder surface with problem.LinearTerm."""
 import numpy as np
 import pytest
@@ -39,7 +39,7 @@ def _problem(model, N, seeds):
     return batch, P, consts
 
 
-@pytest.mark.parametrize("model", ["srbd13", "srbd37", "lip30"])
+@pytest.mark.parametrize("model", ["srbd13", "srbd37", "lip30", "srbd61"])
 def test_knots_with_extra_rows(model):
     N = 20
     batch, P, consts = _problem(model, N, [0])
@@ -63,7 +63,7 @@ def test_knots_with_extra_rows(model):
             np.testing.assert_allclose(H[i], np.block([[lxx, lux.T], [lux, luu]]), rtol=1e-11, atol=1e-7)
 
 
-@pytest.mark.parametrize("model,N,B,wps", [("srbd13", 30, 48, 1), ("srbd13", 30, 48, 2), ("srbd37", 20, 16, 2), ("srbd37", 60, 4, 1), ("lip30", 20, 12, 1)])
+@pytest.mark.parametrize("model,N,B,wps", [("srbd13", 30, 48, 1), ("srbd13", 30, 48, 2), ("srbd37", 20, 16, 2), ("srbd37", 60, 4, 1), ("lip30", 20, 12, 1), ("srbd61", 20, 6, 1)])
 def test_solves_with_extra_rows_match_the_c_oracle(model, N, B, wps):
     batch, P, consts = _problem(model, N, np.arange(B) + 1)
     eng = DdpEngine(model, N, B, opts=dict(OPTS, waves_per_simd=wps), consts=consts)

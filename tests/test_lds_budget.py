@@ -22,6 +22,7 @@ def test_two_instances_of_the_reference_problem_fit_one_cu(tmp_path):
     assert 2 * rows["srbd37S"][0] <= cu and 2 * rows["srbd37B"][0] <= cu            # second-order and barrier builds too
     assert 2 * rows["lip30"][0] <= cu
     assert rows["srbd61"][0] <= 147 * 1024                                          # contact_model = 4 (W-free layout, 149.9 KB): one workgroup per CU
+    assert rows["srbd61"][0] < rows["srbd61X"][0] <= cu                             # ... and with the 8 user rows (157.2 KB) it still fits
     assert 8 * rows["srbd13"][0] <= cu                                              # one-wave kernel: eight wavefronts per CU
     for name, (nbytes, work, two) in rows.items():
         assert nbytes <= cu, name

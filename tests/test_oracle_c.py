@@ -190,3 +190,26 @@ def test_c_oracle_without_relative_velocity_constraints_matches_numpy(model, N):
         assert np.max(np.abs(xs[b] - r.xs)) <= 1e-8 and np.max(np.abs(us[b] - r.us)) <= 1e-8
     if model == "srbd37":
         assert np.max(np.abs(xs - xs1)) > 1e-6          # and it is another problem than the one with the constraints
+
+
+@pytest.mark.parametrize("model,N", [("srbd13", 12), ("srbd37", 8), ("lip30", 10), ("srbd61", 8)])
+def test_c_oracle_with_user_rows_matches_numpy(model, N):
+    """user-declared linear rows (sddp.h extra_*; ddp.py:183-196 sums whatever residual the container holds): the C restatement
+    (xr_rows) against the numpy one (WithLinearRows) on every model -- a state row with a per-knot reference and a dense stage row"""
+    from srbd_horizon_amd import workload
+    nx, nu, npb = cport.DIMS[model]
+    batch = workload.make_batch(model, N, [3])
+    rng = np.random.default_rng(5)
+    a0 = np.zeros(nx + nu); a0[0] = 1.0
+    a3 = np.zeros(nx + nu); a3[:nx] = 0.05 * rng.standard_normal(nx); a3[nx:] = 0.05 * rng.standard_normal(nu)
+    rows = (dict(a=a0, w=2e3, kind="state", const=0.0), dict(a=a3, w=40.0, kind="stage", const=-0.2))
+    P = np.concatenate([batch["params"], np.zeros((1, N + 1, 8))], axis=2)
+    P[:, :, npb] = 0.02 * np.sin(np.arange(N + 1) / 5.0)[None]
+    cst = omodels.RobotConsts(**dict(batch["consts"], extra_rows=rows))
+    o = oddp.DdpOptions(max_iters=100, alpha_converge_threshold=1e-12, beta=1e-3)
+    r = oddp.solve(omodels.make_model(model, cst), batch["x0"][0], P[0], batch["xs"][0], batch["us"][0], o)
+    xo, uo, so = cport.solve_batch(cst, o, batch["x0"], P, batch["xs"], batch["us"], threads=1, model=model)
+    assert r.converged and int(so[0, 1]) == r.iters and int(so[0, 2]) == 1
+    assert np.max(np.abs(r.xs - xo[0])) <= 1e-9 and np.max(np.abs(r.us - uo[0])) <= 1e-9 and abs(r.cost - so[0, 0]) <= 1e-11 * abs(r.cost)
+    plain = cport.solve_batch(omodels.RobotConsts(**batch["consts"]), o, batch["x0"], batch["params"], batch["xs"], batch["us"], threads=1, model=model)
+    assert np.max(np.abs(plain[0][0] - xo[0])) > 1e-5            # the rows act
