@@ -27,7 +27,7 @@ extern "C" {
 #define SDDP_MODEL_SRBD37 1 /* nx=37 nu=24 np=19 : reference SRBD problem, prb.py:16-246                        */
 #define SDDP_MODEL_LIP30  2 /* nx=30 nu=15 np=11 : reference LIP problem,  prb.py:248-441                       */
 #define SDDP_MODEL_SRBD61 3 /* nx=61 nu=48 np=27 : reference SRBD problem at its code-default contact_model = 4
-                               (nc = 8, prb.py:39-41); default build only (no barrier, no second_order = 2)        */
+                               (nc = 8, prb.py:39-41); no second_order = 2 build, no bound barrier (109 > 64) */
 
 /* status codes */
 #define SDDP_OK 0
@@ -108,7 +108,7 @@ typedef struct sddp_model_consts {
      * stage node, exp(exp_parameter (v - upper)) + exp(exp_parameter (lower - v)) with exp_parameter = 6 (ddp.py:182); prb.py sets
      * no bounds.  bound_barrier_weight = 0 (default) = the reference's behaviour.  > 0 adds weight * that sum over the entries of
      * z = [x u] whose bound is finite (lower[j] / upper[j], j < nx + nu; -inf / +inf = unbounded), Gauss-Newton Hessians like every
-     * other cost.  SRBD models only. */
+     * other cost.  srbd13 and srbd37 only (lower / upper hold 64 entries of z). */
     double bound_barrier_weight;       /* 0 = off */
     double bound_barrier_sharpness;    /* 6 */
     double lower[64];

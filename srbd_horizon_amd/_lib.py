@@ -118,13 +118,13 @@ INSTANCES = [
     ("srbd37", "Srbd37", "srbd37"), ("srbd37_b", "Srbd37B", "srbd37"), ("srbd37_s", "Srbd37S", "srbd37"), ("srbd37_bs", "Srbd37BS", "srbd37"),
     ("lip30", "Lip30", "lip30"), ("srbd61", "Srbd61", "srbd61"),
     ("srbd13_x", "Srbd13X", "srbd13"), ("srbd37_x", "Srbd37X", "srbd37"), ("lip30_x", "Lip30X", "lip30"),    # user rows (n_extra > 0)
-    ("srbd61_x", "Srbd61X", "srbd61"),
+    ("srbd61_x", "Srbd61X", "srbd61"), ("srbd61_b", "Srbd61B", "srbd61"),    # srbd61: user rows; friction-cone barrier
 ]
 # Per-build compiler options.  srbd61 (one workgroup per CU, 512 registers a lane, still 1.8 KB of scratch): LLVM's
 # -sink-insts-to-avoid-spills moves hoisted loop-invariant address arithmetic back into the loops instead of spilling it:
 # 25.8 -> 27.3 k solves/s when it went in, 31.8 -> 32.3 k on the round's final kernel (profiles/r04/experiments/README.md).  Measured and NOT applied elsewhere: srbd13 -1 % (scratch 524 -> 288 B
 # but slower), srbd37 +2.3 % in the two-per-SIMD build and -3 % in the other, which share a translation unit.
-INSTANCE_FLAGS = {"srbd61": ["-mllvm", "-sink-insts-to-avoid-spills"], "srbd61_x": ["-mllvm", "-sink-insts-to-avoid-spills"]}
+INSTANCE_FLAGS = {k: ["-mllvm", "-sink-insts-to-avoid-spills"] for k in ("srbd61", "srbd61_x", "srbd61_b")}
 HEADERS = ["sddp_kernels.hpp", "sddp_kernels_mw.hpp", "sddp_models.hpp", "sddp_sort.hpp", "sddp_handle.hpp", "sddp_launch.hpp", "sddp_kernels_host.hpp"]
 
 

@@ -33,6 +33,7 @@ const ModelOps* ops_srbd61();
 const ModelOps* ops_srbd13_x();
 const ModelOps* ops_srbd37_x();
 const ModelOps* ops_srbd61_x();
+const ModelOps* ops_srbd61_b();
 const ModelOps* ops_lip30_x();
 
 std::string& create_error() {
@@ -99,7 +100,7 @@ const ModelOps* model_ops(int id, bool bar = false, bool so2 = false, bool xr = 
         case SDDP_MODEL_SRBD13: return so2 ? (bar ? ops_srbd13_bs() : ops_srbd13_s()) : (bar ? ops_srbd13_b() : ops_srbd13());
         case SDDP_MODEL_SRBD37: return so2 ? (bar ? ops_srbd37_bs() : ops_srbd37_s()) : (bar ? ops_srbd37_b() : ops_srbd37());
         case SDDP_MODEL_LIP30: return ops_lip30();
-        case SDDP_MODEL_SRBD61: return (bar || so2) ? nullptr : ops_srbd61();
+        case SDDP_MODEL_SRBD61: return so2 ? nullptr : (bar ? ops_srbd61_b() : ops_srbd61());   // no second_order = 2 build: LDS is full
         default: return nullptr;
     }
 }
@@ -266,15 +267,16 @@ int sddp_create(sddp_handle** out, int model_id, int N, int batch, const sddp_op
     if (!out) return fail(nullptr, SDDP_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (!model_ops(model_id)) return fail(nullptr, SDDP_ERR_MODEL, "unknown model_id");
-    if (consts && consts->bound_barrier_weight > 0.0 && model_id == SDDP_MODEL_LIP30)
-        return fail(nullptr, SDDP_ERR_ARG, "bound_barrier_weight > 0: the bound barrier exists for the SRBD models only");
+    if (consts && consts->bound_barrier_weight > 0.0 && (model_id == SDDP_MODEL_LIP30 || model_id == SDDP_MODEL_SRBD61))
+        return fail(nullptr, SDDP_ERR_ARG, "bound_barrier_weight > 0: the bound barrier exists for srbd13 and srbd37 only (lower / upper hold 64 "
+                                           "entries of z; srbd61 has 109)");
     // barrier builds: the friction-cone barrier and / or the bound barrier
     const bool bar = consts && (consts->friction_barrier_weight > 0.0 || consts->bound_barrier_weight > 0.0) && !single_build(model_id);
     const bool so2 = opts && opts->second_order == 2 && !single_build(model_id);     // (the LIP model is linear-quadratic: nothing to add)
     const bool xr = consts && consts->n_extra != 0;
     const ModelOps* ops = model_ops(model_id, bar, so2, xr);
     if (!ops) return fail(nullptr, SDDP_ERR_ARG, xr ? "user rows (n_extra > 0) exist for the plain builds only (no barrier, no second_order = 2)"
-                                                    : "this model has no barrier / second_order = 2 build (srbd61: default build only)");
+                                                    : "this model has no such build (srbd61: no second_order = 2 build)");
     const Dims d = ops->dims;
     if (N < 1 || batch < 1) return fail(nullptr, SDDP_ERR_ARG, "N and batch must be >= 1");
     if (xr) { const char* msg = check_extra(*consts, d.nx, d.nu); if (msg) return fail(nullptr, SDDP_ERR_ARG, msg); }

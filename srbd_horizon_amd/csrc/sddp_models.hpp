@@ -317,7 +317,9 @@ struct SrbdModel {
     // parameters in creation order (ddp.py:173-177): rdot_ref(3) w_ref(3) otg(1) (c_ref_i, cdot_switch_i) x NC, oref(4)
     static constexpr int NPB = CS ? 11 + 2 * NC : 19, NP = NPB + NXR;
     static_assert((CS && (NC == 4 || NC == 8)) || (!CS && NC == 2), "srbd37 / srbd61 / srbd13");
-    static_assert(!BAR_ || (CS ? 13 + 12 * NC : 13 + 3 * NC) <= 64, "the bound barrier's masks cover 64 entries of z");
+    // the bound barrier's masks and bound arrays (sddp_model_consts.lower / upper) cover 64 entries of z: models with more
+    // (srbd61: 109) take the friction-cone barrier only -- sddp_create refuses bound_barrier_weight > 0 for them, as the oracle does
+    static constexpr bool BOX = BAR_ && (CS_ ? 13 + 12 * NC_ : 13 + 3 * NC_) <= 64;
     // relative-velocity penalty pairs (prb.py:166-170): q-th pair = (first contact of the leg, its i-th other contact)
     static constexpr int NRV = CS ? 2 * (CM - 1) : 0, CM1 = CM > 1 ? CM - 1 : 1;
     __device__ __forceinline__ static constexpr int rv_a(int q) { return (q / CM1) * CM; }
@@ -460,20 +462,25 @@ struct SrbdModel {
     template <class XV, class UV>
     __device__ __forceinline__ static double bound_cost(const DevConsts& c, XV x, UV u, double* grad = nullptr, double* hdiag = nullptr) {
         double L = 0.0;
-        if (c.box_w > 0.0) {
-            const double ws = c.box_w * c.box_s, k2 = 0.5 * ws * c.box_s;
+        bool on = false;
+        if constexpr (BOX) {
+            if (c.box_w > 0.0) {
+                on = true;
+                const double ws = c.box_w * c.box_s, k2 = 0.5 * ws * c.box_s;
 #pragma unroll
-            for (int j = 0; j < NZ; ++j) {
-                const double z = j < NX ? x[j < NX ? j : 0] : u[j < NX ? 0 : j - NX];
-                double eu = 0.0, el = 0.0;
-                if ((c.box_um >> j) & 1) eu = exp(c.box_s * (z - c.box[64 + j]));
-                if ((c.box_lm >> j) & 1) el = exp(c.box_s * (c.box[j] - z));
-                L += eu + el;
-                if (grad) grad[j] += ws * (eu - el);
-                if (hdiag) hdiag[j] = k2 * (eu + el);
+                for (int j = 0; j < NZ; ++j) {
+                    const double z = j < NX ? x[j < NX ? j : 0] : u[j < NX ? 0 : j - NX];
+                    double eu = 0.0, el = 0.0;
+                    if ((c.box_um >> j) & 1) eu = exp(c.box_s * (z - c.box[64 + j]));
+                    if ((c.box_lm >> j) & 1) el = exp(c.box_s * (c.box[j] - z));
+                    L += eu + el;
+                    if (grad) grad[j] += ws * (eu - el);
+                    if (hdiag) hdiag[j] = k2 * (eu + el);
+                }
+                L *= c.box_w;
             }
-            L *= c.box_w;
-        } else if (hdiag) {
+        }
+        if (!on && hdiag) {
 #pragma unroll
             for (int j = 0; j < NZ; ++j) hdiag[j] = 0.0;
         }
@@ -1647,11 +1654,12 @@ using Srbd13S = SrbdModel<2, false, false, true>;   // full second-order builds 
 using Srbd37S = SrbdModel<4, true, false, true>;
 using Srbd13BS = SrbdModel<2, false, true, true>;    // barrier + full second order
 using Srbd37BS = SrbdModel<4, true, true, true>;
-using Srbd61 = SrbdModel<8, true>;                  // contact_model = 4 (prb.py:39-41): default build only
+using Srbd61 = SrbdModel<8, true>;                  // contact_model = 4 (prb.py:39-41); Srbd61X / Srbd61B below, no second_order = 2 build
 using Lip30 = LipModel<>;
 using Srbd13X = SrbdModel<2, false, false, false, kXrRows>;   // with user-declared linear residual rows (sddp_model_consts.n_extra > 0)
 using Srbd37X = SrbdModel<4, true, false, false, kXrRows>;
 using Lip30X = LipModel<kXrRows>;
 using Srbd61X = SrbdModel<8, true, false, false, kXrRows>;
+using Srbd61B = SrbdModel<8, true, true>;            // friction-cone barrier only (BOX = false)
 
 }  // namespace sddp

@@ -120,5 +120,5 @@ def test_bound_barrier_through_the_problem_facade_and_error_paths():
         DdpEngine("srbd13", N, 1, consts=dict(bound_barrier_weight=-1.0))
     with pytest.raises(RuntimeError, match="lower"):
         DdpEngine("srbd13", N, 1, consts=dict(bound_barrier_weight=1.0, lower=np.full(19, 1.0), upper=np.full(19, 0.0)))
-    with pytest.raises(RuntimeError, match="SRBD models only"):
+    with pytest.raises(RuntimeError, match="srbd13 and srbd37 only"):
         DdpEngine("lip30", 20, 1, consts=dict(bound_barrier_weight=1.0))

@@ -404,7 +404,7 @@ def test_extreme_horizons_and_ragged_batches(name, N, B):
 BARRIER = dict(friction_barrier_weight=6.0, friction_barrier_sharpness=30.0, friction_cone_coefficient=0.8)
 
 
-@pytest.mark.parametrize("name", ["srbd13", "srbd37"])
+@pytest.mark.parametrize("name", ["srbd13", "srbd37", "srbd61"])
 def test_friction_cone_barrier_knots_match_oracle(name):
     """SURVEY 8(f) item 3 -- the inequality handling the reference disables (prb.py:172-177, ddp.py:197-202), as an opt-in
     exponential barrier on the contact forces: per-knot value, gradient and Gauss-Newton Hessian of the barrier builds."""
@@ -429,7 +429,7 @@ def test_friction_cone_barrier_knots_match_oracle(name):
         np.testing.assert_allclose(H[t], Ho, rtol=1e-11, atol=1e-11 * max(1.0, np.max(np.abs(Ho))))
 
 
-@pytest.mark.parametrize("name,N", [("srbd13", 30), ("srbd37", 20)])
+@pytest.mark.parametrize("name,N", [("srbd13", 30), ("srbd37", 20), ("srbd61", 12)])
 def test_friction_cone_barrier_solve_matches_oracle_and_tightens_the_cone(name, N):
     seeds = [0, 1, 6]
     batch = workload.make_batch(name, N, seeds)
@@ -448,11 +448,14 @@ def test_friction_cone_barrier_solve_matches_oracle_and_tightens_the_cone(name, 
         assert abs(st["cost"][b] - r.cost) <= 1e-9 * abs(r.cost)
     # worst violation of the linearised cone A f <= 0 over all knots and contacts shrinks when the barrier is on
     A = omodels.friction_cone_rows(0.8)
-    fcols = [slice(3 * i, 3 * i + 3) for i in range(2)] if name == "srbd13" else [slice(6 * i + 3, 6 * i + 6) for i in range(4)]
+    fcols = [slice(3 * i, 3 * i + 3) for i in range(2)] if name == "srbd13" else [slice(6 * i + 3, 6 * i + 6) for i in range(4 if name == "srbd37" else 8)]
     viol = {t: max(float(np.max(res[t][1][..., c] @ A.T)) for c in fcols) for t in res}
     assert viol["on"] < viol["off"] or viol["off"] <= 0.0, viol
     with pytest.raises(RuntimeError, match="friction"):
         DdpEngine(name, N, 1, consts=dict(friction_barrier_weight=-1.0))
+    if name == "srbd61":          # lower / upper hold 64 entries of z, this model has 109: friction-cone barrier only
+        with pytest.raises(RuntimeError, match="bound barrier"):
+            DdpEngine(name, N, 1, consts=dict(bound_barrier_weight=1.0))
 
 
 @pytest.mark.parametrize("name,N,seeds", [("srbd13", 30, [0, 1, 2, 4, 6]), ("srbd37", 20, [3, 5])])

@@ -10,7 +10,7 @@ template <class M> void show(const char* n) {
     std::printf("%s %zu %d %d\n", n, L::BYTES, L::WORK, int(2 * L::BYTES <= size_t(160) * 1024));
 }
 int main() {
-    show<Srbd37>("srbd37"); show<Srbd37B>("srbd37B"); show<Srbd37S>("srbd37S"); show<Srbd37BS>("srbd37BS"); show<Lip30>("lip30"); show<Srbd61>("srbd61"); show<Srbd37X>("srbd37X"); show<Lip30X>("lip30X"); show<Srbd61X>("srbd61X");
+    show<Srbd37>("srbd37"); show<Srbd37B>("srbd37B"); show<Srbd37S>("srbd37S"); show<Srbd37BS>("srbd37BS"); show<Lip30>("lip30"); show<Srbd61>("srbd61"); show<Srbd37X>("srbd37X"); show<Lip30X>("lip30X"); show<Srbd61X>("srbd61X"); show<Srbd61B>("srbd61B");
     std::printf("srbd13 %zu %d %d\n", Lds<Srbd13>::BYTES, 0, 1);
     return 0;
 }
