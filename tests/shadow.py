@@ -269,6 +269,12 @@ def check_batch(model, N, batch, opts, engine_over, cst, threads=16):
     st = eng.stats.copy()
     qi = eng.queue_info()
     eng.close()
+    return compare_batch(model, N, batch, opts, engine_over, cst, x, u, st, threads, queue_info=qi)
+
+
+def compare_batch(model, N, batch, opts, engine_over, cst, x, u, st, threads=16, queue_info=None):
+    """The oracle side of check_batch for results (x, u, st) the engine has already produced from `batch` (x0, params, xs, us,
+    consts) -- e.g. one tick of a device-resident receding-horizon loop, whose inputs the caller has rebuilt on the host."""
     o = oddp.DdpOptions(**opts)
     xo, uo, so = cport.solve_batch(cst, o, batch["x0"], batch["params"], batch["xs"], batch["us"], threads=threads, model=model)
     _, _, sf = cport.solve_batch(cst, o, batch["x0"], batch["params"], batch["xs"], batch["us"], threads=threads, model=model,
@@ -277,7 +283,7 @@ def check_batch(model, N, batch, opts, engine_over, cst, threads=16):
     same = st["iters"] == it_o
     idx = np.nonzero(~same)[0]
     explained = explain_divergent(model, N, opts, engine_over, batch["consts"], cst, batch, idx) if idx.size else []
-    return dict(x=x, u=u, st=st, xo=xo, uo=uo, so=so, same=same, explained=explained, queue_info=qi,
+    return dict(x=x, u=u, st=st, xo=xo, uo=uo, so=so, same=same, explained=explained, queue_info=queue_info,
                 n_cpu_pair=int((sf[:, 1] != so[:, 1]).sum()), cpu_pair_idx=np.nonzero(sf[:, 1] != so[:, 1])[0])
 
 
