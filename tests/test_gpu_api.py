@@ -256,7 +256,7 @@ def test_fleet_tick_of_1024_robots_matches_the_c_oracle_tick_by_tick(record_prop
     previous solution shifted by one knot on the device, new last parameter column and measured state uploaded) +
     sddp_solve_resident, against the C oracle solving the same tick from the HOST-side shift of the same data
     (dsrbd_example.py:102-135).  The oracle is fed the GPU's previous solution, so every tick is compared on its own."""
-    N, B, ticks = 30, 1024, 6
+    N, B, ticks = 30, 1024, int(os.environ.get("SDDP_SOAK_TICKS", "6"))      # (a soak run by hand: 200 ticks)
     b = workload.make_batch("srbd13", N, np.arange(B) + 20000)
     eng = DdpEngine("srbd13", N, B, opts=dict(OPTS, waves_per_simd=1))
     eng.set_initial_state(b["x0"]); eng.set_x_warmstart(b["xs"]); eng.set_u_warmstart(b["us"])
